@@ -1,0 +1,89 @@
+"""ctypes binding of libddpm_mi355x.so (declared in include/ddpm_mi355x.h).
+
+There is deliberately no fallback: if the library is missing or a call fails, an exception is
+raised. Device pointers are passed as integers (tensor.data_ptr()).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libddpm_mi355x.so")
+
+P, I32, I64, F32, F64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, I32) for n in ("batch", "in_h", "in_w", "c1", "ld1", "c2", "ld2", "cout", "ldo", "act", "ldr",
+                                   "out_h", "out_w", "off_y", "off_x")]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("scale", P), ("shift", P), ("residual", P), ("temb", P)]
+
+
+class EmbedArgs(C.Structure):
+    _fields_ = [("batch", I32), ("emb_dim", I32), ("n_labels", I32), ("t_is_float", I32),
+                ("t", P), ("y", P), ("label_table", P),
+                ("ch", I32 * 4), ("w", P * 4), ("b", P * 4), ("lw", P * 4), ("lb", P * 4),
+                ("out", P * 4), ("emb_out", P)]
+
+
+_SIGNATURES = {
+    "ddpm_abi_version": [],
+    "ddpm_schedule_betas": [I32, I32, F64, F64, P],
+    "ddpm_schedule_tables": [I32, P, P, P],
+    "ddpm_step_coefficients": [F32, F32, F32, P],
+    "ddpm_reverse_step": [P, P, P, F32, P, F32, F32, F32, P, I64, P],
+    "ddpm_add_noise": [P, P, P, P, I32, P, I32, I64, P],
+    "ddpm_mse_partial_count": [],
+    "ddpm_mse_fwd": [P, P, I64, P, P, P],
+    "ddpm_mse_bwd": [P, P, P, I64, P, P],
+    "ddpm_time_embed": [C.POINTER(EmbedArgs), P],
+    "ddpm_sinusoidal_embedding": [P, I32, I32, I32, P, P],
+    "ddpm_conv3x3_fwd": [C.POINTER(ConvDesc), P, P, P, C.POINTER(Epilogue), P, P],
+    "ddpm_conv1x1_fwd": [C.POINTER(ConvDesc), P, P, P, C.POINTER(Epilogue), P, P],
+    "ddpm_convT2x2_fwd": [C.POINTER(ConvDesc), P, P, C.POINTER(Epilogue), P, P],
+    "ddpm_pack_conv3x3": [P, I32, I32, I32, P, P],
+    "ddpm_pack_convT2x2": [P, I32, I32, P, P],
+    "ddpm_conv3x3_first_fwd": [P, P, C.POINTER(Epilogue), I32, P, I32, I32, I32, I32, I32, I32, P],
+    "ddpm_conv1x1_final_fwd": [P, I32, P, P, P, I32, I32, I32, I32, I32, P],
+    "ddpm_pool_skip_fwd": [P, I32, P, P, I32, P, I32, P, I32, I32, I32, I32, P],
+    "ddpm_add_temb": [P, I32, P, P, I32, I32, I32, I32, P],
+    "ddpm_attention_fwd": [P, P, I32, P, P, I32, P, P, P, I32, I32, I32, I32, P],
+}
+
+_lib = None
+
+
+class DdpmError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DdpmError(f"{LIB_PATH} is missing: build it with `python diffusion-model_amd/build.py` "
+                            "(there is no CPU fallback for the HIP path)")
+        handle = C.CDLL(LIB_PATH)
+        handle.ddpm_last_error.restype = C.c_char_p
+        handle.ddpm_last_error.argtypes = []
+        for name, sig in _SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the header and library disagree
+            fn.argtypes = sig
+            fn.restype = C.c_int
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return ["ddpm_last_error"] + list(_SIGNATURES)
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise DdpmError with the library's message on failure."""
+    h = lib()
+    rc = getattr(h, name)(*args)
+    if rc != 0:
+        raise DdpmError(f"{name} failed ({rc}): {h.ddpm_last_error().decode()}")
+    return rc

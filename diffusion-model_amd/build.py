@@ -1,0 +1,63 @@
+"""Builds libddpm_mi355x.so (gfx950 only) from csrc/ with hipcc. No torch involved.
+
+    python diffusion-model_amd/build.py [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libddpm_mi355x.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+         "-Wno-unused-function", "-fno-gpu-rdc"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+    hdrs.append(os.path.join(HERE, "..", "include", "ddpm_mi355x.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, force, hdr_mtime):
+    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    path = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_mtime):
+        return obj, False
+    cmd = [HIPCC, *FLAGS, "-x", "hip", "-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build_library(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_mtime = _deps_mtime()
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force, hdr_mtime), srcs))
+    objs = [o for o, _ in res]
+    if any(c for _, c in res) or not os.path.exists(LIB) or force:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"built {LIB} ({sum(c for _, c in res)} of {len(srcs)} sources recompiled)")
+    elif verbose:
+        print(f"{LIB} up to date")
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)

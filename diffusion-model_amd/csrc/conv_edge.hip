@@ -1,0 +1,127 @@
+// The two thin layers at the edges of the UNet, which are not GEMM-shaped enough for the matrix
+// cores: the first 3x3 conv (1 or 3 input channels, NCHW image in, NHWC out) and the final 1x1
+// conv (NHWC in, 1 or 3 channels, NCHW out). Both are memory-bound.
+#include "common.h"
+
+using ddpm::as_stream;
+
+namespace {
+
+constexpr int kMaxLdsFloats = 12288;  // 48 KB of weights staged per workgroup
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == DDPM_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == DDPM_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    return v;
+}
+
+// One thread = one pixel x 4 consecutive output channels. Weights sit in LDS as [ci*9+tap][cout].
+__global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ residual_unused, const float* __restrict__ temb,
+                                                             int act, float* __restrict__ out, int batch, int cin, int h, int wd,
+                                                             int cout, int ldo) {
+    __shared__ __attribute__((aligned(16))) float sw[kMaxLdsFloats];
+    const int kt = cin * 9;
+    for (int i = threadIdx.x; i < kt * cout; i += blockDim.x) {
+        const int co = i % cout, k = i / cout;  // k = ci*9 + tap
+        sw[i] = w[static_cast<int64_t>(co) * kt + k];
+    }
+    __syncthreads();
+    const int c4n = cout >> 2;
+    const int64_t total = static_cast<int64_t>(batch) * h * wd * c4n;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int c4 = static_cast<int>(idx % c4n);
+        const int64_t pix = idx / c4n;
+        const int xx = static_cast<int>(pix % wd);
+        const int yy = static_cast<int>((pix / wd) % h);
+        const int b = static_cast<int>(pix / (static_cast<int64_t>(wd) * h));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* plane = x + (static_cast<int64_t>(b) * cin + ci) * h * wd;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
+                const float v = (y2 >= 0 && y2 < h && x2 >= 0 && x2 < wd) ? plane[y2 * wd + x2] : 0.f;
+                const float4 wv = *reinterpret_cast<const float4*>(sw + (ci * 9 + tap) * cout + c4 * 4);
+                acc.x += v * wv.x; acc.y += v * wv.y; acc.z += v * wv.z; acc.w += v * wv.w;
+            }
+        }
+        float r[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = c4 * 4 + e;
+            float v = r[e] * (scale ? scale[n] : 1.0f) + (shift ? shift[n] : 0.0f);
+            v = act_apply(v, act);
+            if (temb) v += temb[static_cast<int64_t>(b) * cout + n];
+            r[e] = v;
+        }
+        *reinterpret_cast<float4*>(out + pix * ldo + c4 * 4) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+// 16 lanes per pixel, each holding 4 channels of a 64-channel slab; weights in LDS as [cout][c].
+__global__ __launch_bounds__(256) void conv1x1_final_kernel(const float* __restrict__ x, int ld, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int batch,
+                                                             int hw, int c, int cout) {
+    __shared__ __attribute__((aligned(16))) float sw[kMaxLdsFloats];
+    for (int i = threadIdx.x; i < c * cout; i += blockDim.x) sw[i] = w[i];
+    __syncthreads();
+    const int sub = threadIdx.x & 15;
+    const int64_t npix = static_cast<int64_t>(batch) * hw;
+    const int64_t groups = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 4);
+    // every lane of a wave iterates the same number of times (shuffles need all 16 lanes of a group)
+    const int64_t iters = (npix + groups - 1) / groups;
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t pix = it * groups + static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 4) + (threadIdx.x >> 4);
+        const bool live = pix < npix;
+        for (int co = 0; co < cout; ++co) {
+            float acc = 0.f;
+            if (live) {
+                for (int c0 = sub * 4; c0 < c; c0 += 64) {
+                    const float4 v = *reinterpret_cast<const float4*>(x + pix * ld + c0);
+                    const float4 wv = *reinterpret_cast<const float4*>(sw + co * c + c0);
+                    acc += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+                }
+            }
+            acc += __shfl_xor(acc, 8);
+            acc += __shfl_xor(acc, 4);
+            acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 1);
+            if (live && sub == 0) {
+                const int64_t b = pix / hw, q = pix % hw;
+                out[(b * cout + co) * hw + q] = acc + (bias ? bias[co] : 0.f);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ddpm_conv3x3_first_fwd(const float* x_nchw, const float* w, const ddpm_epilogue* ep, int act, float* out, int batch,
+                                      int cin, int h, int w_, int cout, int ldo, void* stream) {
+    DDPM_REQUIRE(x_nchw && w && ep && out && batch > 0 && cin > 0 && h > 0 && w_ > 0 && cout > 0);
+    DDPM_REQUIRE((cout & 3) == 0 && (ldo & 3) == 0 && ldo >= cout && ddpm::aligned16(out));
+    DDPM_REQUIRE(cin * 9 * cout <= kMaxLdsFloats);
+    DDPM_REQUIRE(!ep->residual && (!ep->scale || ep->shift));
+    DDPM_REQUIRE(act >= DDPM_ACT_NONE && act <= DDPM_ACT_GELU);
+    const int64_t total = static_cast<int64_t>(batch) * h * w_ * (cout / 4);
+    int64_t grid = (total + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    conv3x3_first_kernel<<<static_cast<int>(grid), 256, 0, as_stream(stream)>>>(x_nchw, w, ep->scale, ep->shift, nullptr, ep->temb,
+                                                                               act, out, batch, cin, h, w_, cout, ldo);
+    return ddpm::check_launch("conv3x3_first_kernel");
+}
+
+extern "C" int ddpm_conv1x1_final_fwd(const float* x, int ld, const float* w, const float* bias, float* out_nchw, int batch, int h,
+                                      int w_, int c, int cout, void* stream) {
+    DDPM_REQUIRE(x && w && out_nchw && batch > 0 && h > 0 && w_ > 0 && c > 0 && cout > 0);
+    DDPM_REQUIRE((c & 3) == 0 && (ld & 3) == 0 && ld >= c && ddpm::aligned16(x));
+    DDPM_REQUIRE(c * cout <= kMaxLdsFloats);
+    const int64_t npix = static_cast<int64_t>(batch) * h * w_;
+    int64_t grid = (npix + 15) / 16;
+    if (grid > 256 * 16) grid = 256 * 16;
+    conv1x1_final_kernel<<<static_cast<int>(grid), 256, 0, as_stream(stream)>>>(x, ld, w, bias, out_nchw, batch, h * w_, c, cout);
+    return ddpm::check_launch("conv1x1_final_kernel");
+}

@@ -1,0 +1,292 @@
+// HBM-bound elementwise kernels of the diffusion process: reverse ancestral step, forward noising,
+// eps-MSE loss, max-pool + skip hand-off, time-embedding broadcast add.
+#include "common.h"
+
+using ddpm::as_stream;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__host__ inline int grid_for(int64_t work_items, int per_block, int cap = 256 * 16) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return static_cast<int>(g);
+}
+
+// ---- reverse step ---------------------------------------------------------------------------
+// The reference evaluates c1*(x - c2*eps) + c3*z as five separately rounded fp32 operations;
+// the explicit _rn intrinsics keep the compiler from contracting them into FMAs.
+__device__ __forceinline__ float guided_eps(float e_c, float e_u, float w, bool low) {
+    // torch.lerp(start=e_u, end=e_c, weight=w)
+    const float d = __fsub_rn(e_c, e_u);
+    return low ? __fadd_rn(e_u, __fmul_rn(w, d)) : __fsub_rn(e_c, __fmul_rn(d, __fsub_rn(1.0f, w)));
+}
+
+__device__ __forceinline__ float step1(float x, float e, float z, float c1, float c2, float c3, bool has_z) {
+    const float inner = __fsub_rn(x, __fmul_rn(c2, e));
+    const float a = __fmul_rn(c1, inner);
+    // t == 0: the reference still adds sqrt(beta)*0 = +0, which leaves `a` unchanged except that
+    // -0 + +0 = +0; adding 0.0f reproduces exactly that.
+    return has_z ? __fadd_rn(a, __fmul_rn(c3, z)) : __fadd_rn(a, 0.0f);
+}
+
+template <bool HAS_Z, bool HAS_U>
+__global__ __launch_bounds__(kThreads) void reverse_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                                 const float* __restrict__ eps_u, float w,
+                                                                 const float* __restrict__ z, float c1, float c2, float c3,
+                                                                 float* __restrict__ out, int64_t n) {
+    const bool low = fabsf(w) < 0.5f;
+    const int64_t n4 = n >> 2;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float4 ev = reinterpret_cast<const float4*>(eps)[i];
+        if (HAS_U) {
+            const float4 uv = reinterpret_cast<const float4*>(eps_u)[i];
+            ev.x = guided_eps(ev.x, uv.x, w, low);
+            ev.y = guided_eps(ev.y, uv.y, w, low);
+            ev.z = guided_eps(ev.z, uv.z, w, low);
+            ev.w = guided_eps(ev.w, uv.w, w, low);
+        }
+        float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (HAS_Z) zv = reinterpret_cast<const float4*>(z)[i];
+        float4 o;
+        o.x = step1(xv.x, ev.x, zv.x, c1, c2, c3, HAS_Z);
+        o.y = step1(xv.y, ev.y, zv.y, c1, c2, c3, HAS_Z);
+        o.z = step1(xv.z, ev.z, zv.z, c1, c2, c3, HAS_Z);
+        o.w = step1(xv.w, ev.w, zv.w, c1, c2, c3, HAS_Z);
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+    // tail (n not a multiple of 4)
+    const int64_t tail0 = n4 << 2;
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid < n - tail0) {
+        const int64_t i = tail0 + gid;
+        float e = eps[i];
+        if (HAS_U) e = guided_eps(e, eps_u[i], w, low);
+        out[i] = step1(x[i], e, HAS_Z ? z[i] : 0.f, c1, c2, c3, HAS_Z);
+    }
+}
+
+// ---- forward noising ------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                              const int64_t* __restrict__ t, const float* __restrict__ abar,
+                                                              int timesteps, float* __restrict__ out, int64_t per_sample,
+                                                              int blocks_per_sample) {
+    const int b = blockIdx.x / blocks_per_sample;
+    const int chunk = blockIdx.x % blocks_per_sample;
+    int64_t ti = t[b];
+    if (ti < 0) ti += timesteps;               // python-style negative index
+    const float ab = abar[ti];
+    const float s1 = __fsqrt_rn(ab);
+    const float s2 = __fsqrt_rn(__fsub_rn(1.0f, ab));
+    const float* xs = x0 + static_cast<int64_t>(b) * per_sample;
+    const float* ns = noise + static_cast<int64_t>(b) * per_sample;
+    float* os = out + static_cast<int64_t>(b) * per_sample;
+    const bool vec = (per_sample & 3) == 0;
+    if (vec) {
+        const int64_t n4 = per_sample >> 2;
+        for (int64_t i = static_cast<int64_t>(chunk) * blockDim.x + threadIdx.x; i < n4;
+             i += static_cast<int64_t>(blocks_per_sample) * blockDim.x) {
+            const float4 a = reinterpret_cast<const float4*>(xs)[i];
+            const float4 e = reinterpret_cast<const float4*>(ns)[i];
+            float4 o;
+            o.x = __fadd_rn(__fmul_rn(s1, a.x), __fmul_rn(s2, e.x));
+            o.y = __fadd_rn(__fmul_rn(s1, a.y), __fmul_rn(s2, e.y));
+            o.z = __fadd_rn(__fmul_rn(s1, a.z), __fmul_rn(s2, e.z));
+            o.w = __fadd_rn(__fmul_rn(s1, a.w), __fmul_rn(s2, e.w));
+            reinterpret_cast<float4*>(os)[i] = o;
+        }
+    } else {
+        for (int64_t i = static_cast<int64_t>(chunk) * blockDim.x + threadIdx.x; i < per_sample;
+             i += static_cast<int64_t>(blocks_per_sample) * blockDim.x)
+            os[i] = __fadd_rn(__fmul_rn(s1, xs[i]), __fmul_rn(s2, ns[i]));
+    }
+}
+
+// ---- MSE ------------------------------------------------------------------------------------
+constexpr int kMsePartials = 1024;
+
+__global__ __launch_bounds__(kThreads) void mse_partial_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                                int64_t n, double* __restrict__ partial) {
+    __shared__ double red[kThreads / 64];
+    double acc = 0.0;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float d = p[i] - y[i];
+        acc += static_cast<double>(d) * static_cast<double>(d);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < kThreads / 64; ++i) s += red[i];
+        partial[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void mse_final_kernel(const double* __restrict__ partial, int count, int64_t n,
+                                                              float* __restrict__ loss) {
+    __shared__ double red[kThreads / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) acc += partial[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < kThreads / 64; ++i) s += red[i];
+        loss[0] = static_cast<float>(s / static_cast<double>(n));
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void mse_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                            const float* __restrict__ gout, int64_t n, float* __restrict__ g) {
+    const float k = gout[0] * (2.0f / static_cast<float>(n));
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+        g[i] = (p[i] - y[i]) * k;
+}
+
+// ---- max-pool 2x2 + skip hand-off -----------------------------------------------------------
+// One thread per (2x2 cell, 4 channels). Cells cover ceil(H/2) x ceil(W/2) so that the last
+// row/column of an odd-sized image still gets its skip value; only complete cells are pooled
+// (floor semantics of MaxPool2d(2,2)).
+__global__ __launch_bounds__(kThreads) void pool_skip_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ temb,
+                                                              float* __restrict__ skip, int lds_, float* __restrict__ pooled,
+                                                              int ldp, uint8_t* __restrict__ argmax, int batch, int h, int w,
+                                                              int c) {
+    const int c4n = c >> 2;
+    const int ch = (h + 1) >> 1, cw = (w + 1) >> 1;
+    const int ph = h >> 1, pw = w >> 1;
+    const int64_t total = static_cast<int64_t>(batch) * ch * cw * c4n;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int c4 = static_cast<int>(idx % c4n);
+        int64_t r = idx / c4n;
+        const int cx = static_cast<int>(r % cw);
+        r /= cw;
+        const int cy = static_cast<int>(r % ch);
+        const int b = static_cast<int>(r / ch);
+        float4 te = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (temb) te = *reinterpret_cast<const float4*>(temb + static_cast<int64_t>(b) * c + c4 * 4);
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 arg = make_uchar4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int y = cy * 2 + (q >> 1), xx = cx * 2 + (q & 1);
+            if (y < h && xx < w) {
+                const int64_t pix = (static_cast<int64_t>(b) * h + y) * w + xx;
+                const float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + c4 * 4);
+                if (skip) {
+                    float4 s;
+                    s.x = v.x + te.x; s.y = v.y + te.y; s.z = v.z + te.z; s.w = v.w + te.w;
+                    *reinterpret_cast<float4*>(skip + pix * lds_ + c4 * 4) = s;
+                }
+                // first maximum in window scan order wins (NaN propagates like torch: v != v)
+                if (v.x > best.x || v.x != v.x) { best.x = v.x; arg.x = q; }
+                if (v.y > best.y || v.y != v.y) { best.y = v.y; arg.y = q; }
+                if (v.z > best.z || v.z != v.z) { best.z = v.z; arg.z = q; }
+                if (v.w > best.w || v.w != v.w) { best.w = v.w; arg.w = q; }
+            }
+        }
+        if (pooled && cy < ph && cx < pw) {
+            const int64_t pp = (static_cast<int64_t>(b) * ph + cy) * pw + cx;
+            *reinterpret_cast<float4*>(pooled + pp * ldp + c4 * 4) = best;
+            if (argmax) *reinterpret_cast<uchar4*>(argmax + pp * c + c4 * 4) = arg;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void add_temb_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ temb,
+                                                             float* __restrict__ y, int ldy, int batch, int hw, int c) {
+    const int c4n = c >> 2;
+    const int64_t total = static_cast<int64_t>(batch) * hw * c4n;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int c4 = static_cast<int>(idx % c4n);
+        const int64_t pix = idx / c4n;
+        const int b = static_cast<int>(pix / hw);
+        const float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + c4 * 4);
+        const float4 te = *reinterpret_cast<const float4*>(temb + static_cast<int64_t>(b) * c + c4 * 4);
+        float4 o;
+        o.x = v.x + te.x; o.y = v.y + te.y; o.z = v.z + te.z; o.w = v.w + te.w;
+        *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int ddpm_reverse_step(const float* x, const float* eps, const float* eps_uncond, float cfg_w, const float* z,
+                                 float c1, float c2, float c3, float* x_out, int64_t n, void* stream) {
+    DDPM_REQUIRE(x && eps && x_out && n >= 0);
+    DDPM_REQUIRE(ddpm::aligned16(x) && ddpm::aligned16(eps) && ddpm::aligned16(x_out));
+    DDPM_REQUIRE(!z || ddpm::aligned16(z));
+    DDPM_REQUIRE(!eps_uncond || ddpm::aligned16(eps_uncond));
+    if (n == 0) return DDPM_OK;
+    const int grid = grid_for((n + 3) / 4, kThreads, 256 * 32);
+    hipStream_t s = as_stream(stream);
+    if (z && eps_uncond)
+        reverse_step_kernel<true, true><<<grid, kThreads, 0, s>>>(x, eps, eps_uncond, cfg_w, z, c1, c2, c3, x_out, n);
+    else if (z)
+        reverse_step_kernel<true, false><<<grid, kThreads, 0, s>>>(x, eps, nullptr, cfg_w, z, c1, c2, c3, x_out, n);
+    else if (eps_uncond)
+        reverse_step_kernel<false, true><<<grid, kThreads, 0, s>>>(x, eps, eps_uncond, cfg_w, nullptr, c1, c2, c3, x_out, n);
+    else
+        reverse_step_kernel<false, false><<<grid, kThreads, 0, s>>>(x, eps, nullptr, cfg_w, nullptr, c1, c2, c3, x_out, n);
+    return ddpm::check_launch("reverse_step_kernel");
+}
+
+extern "C" int ddpm_add_noise(const float* x0, const float* noise, const int64_t* t, const float* alpha_bar, int timesteps,
+                              float* out, int batch, int64_t per_sample, void* stream) {
+    DDPM_REQUIRE(x0 && noise && t && alpha_bar && out && batch >= 0 && per_sample >= 0 && timesteps >= 1);
+    DDPM_REQUIRE(ddpm::aligned16(x0) && ddpm::aligned16(noise) && ddpm::aligned16(out));
+    if (batch == 0 || per_sample == 0) return DDPM_OK;
+    int bps = static_cast<int>((per_sample / 4 + kThreads - 1) / kThreads);
+    if (bps < 1) bps = 1;
+    if (bps > 64) bps = 64;
+    DDPM_REQUIRE(static_cast<int64_t>(batch) * bps < (1ll << 31));
+    add_noise_kernel<<<batch * bps, kThreads, 0, as_stream(stream)>>>(x0, noise, t, alpha_bar, timesteps, out, per_sample, bps);
+    return ddpm::check_launch("add_noise_kernel");
+}
+
+extern "C" int ddpm_mse_partial_count(void) { return kMsePartials; }
+
+extern "C" int ddpm_mse_fwd(const float* pred, const float* target, int64_t n, double* partial, float* loss_out, void* stream) {
+    DDPM_REQUIRE(pred && target && partial && loss_out && n > 0);
+    const int grid = grid_for(n, kThreads * 4, kMsePartials);
+    mse_partial_kernel<<<grid, kThreads, 0, as_stream(stream)>>>(pred, target, n, partial);
+    mse_final_kernel<<<1, kThreads, 0, as_stream(stream)>>>(partial, grid, n, loss_out);
+    return ddpm::check_launch("mse_fwd");
+}
+
+extern "C" int ddpm_mse_bwd(const float* pred, const float* target, const float* gout, int64_t n, float* grad, void* stream) {
+    DDPM_REQUIRE(pred && target && gout && grad && n > 0);
+    mse_bwd_kernel<<<grid_for(n, kThreads * 4), kThreads, 0, as_stream(stream)>>>(pred, target, gout, n, grad);
+    return ddpm::check_launch("mse_bwd_kernel");
+}
+
+extern "C" int ddpm_pool_skip_fwd(const float* x, int ldx, const float* temb, float* skip, int lds_, float* pooled, int ldp,
+                                  uint8_t* argmax, int batch, int h, int w, int c, void* stream) {
+    DDPM_REQUIRE(x && batch > 0 && h > 0 && w > 0 && c > 0 && (c & 3) == 0 && (ldx & 3) == 0);
+    DDPM_REQUIRE(skip || pooled);
+    DDPM_REQUIRE(!skip || ((lds_ & 3) == 0 && lds_ >= c && ddpm::aligned16(skip)));
+    DDPM_REQUIRE(!pooled || ((ldp & 3) == 0 && ldp >= c && ddpm::aligned16(pooled)));
+    DDPM_REQUIRE(ddpm::aligned16(x) && (!temb || ddpm::aligned16(temb)) && ldx >= c);
+    const int64_t total = static_cast<int64_t>(batch) * ((h + 1) / 2) * ((w + 1) / 2) * (c / 4);
+    pool_skip_kernel<<<grid_for(total, kThreads, 256 * 32), kThreads, 0, as_stream(stream)>>>(x, ldx, temb, skip, lds_, pooled, ldp,
+                                                                                            argmax, batch, h, w, c);
+    return ddpm::check_launch("pool_skip_kernel");
+}
+
+extern "C" int ddpm_add_temb(const float* x, int ldx, const float* temb, float* y, int ldy, int batch, int hw, int c,
+                             void* stream) {
+    DDPM_REQUIRE(x && temb && y && batch > 0 && hw > 0 && c > 0 && (c & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0);
+    DDPM_REQUIRE(ldx >= c && ldy >= c && ddpm::aligned16(x) && ddpm::aligned16(y) && ddpm::aligned16(temb));
+    const int64_t total = static_cast<int64_t>(batch) * hw * (c / 4);
+    add_temb_kernel<<<grid_for(total, kThreads, 256 * 32), kThreads, 0, as_stream(stream)>>>(x, ldx, temb, y, ldy, batch, hw, c);
+    return ddpm::check_launch("add_temb_kernel");
+}

@@ -1,0 +1,128 @@
+// Timestep / label conditioning: sinusoidal embedding, then the four time Linears (plus the label
+// Embedding and four label Linears when labels are given). One workgroup per (sample, Linear).
+#include <cmath>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxEmb = 1024;
+
+struct EmbedDev {
+    int batch, emb_dim, n_labels, t_is_float;
+    const void* t;
+    const int64_t* y;
+    const float* label_table;
+    int ch[4];
+    const float* w[4];
+    const float* b[4];
+    const float* lw[4];
+    const float* lb[4];
+    float* out[4];
+    float* emb_out;
+    float log_step;  // fp32: log(10000) / (half - 1)
+};
+
+__global__ __launch_bounds__(256) void time_embed_kernel(const EmbedDev a) {
+    __shared__ float emb[kMaxEmb];
+    __shared__ float lemb[kMaxEmb];
+    const int b = blockIdx.x, which = blockIdx.y;
+    const int E = a.emb_dim, half = E >> 1;
+    const float tv = a.t_is_float ? static_cast<const float*>(a.t)[b]
+                                  : static_cast<float>(static_cast<const int64_t*>(a.t)[b]);
+    for (int i = threadIdx.x; i < 2 * half; i += blockDim.x) {
+        const int k = i < half ? i : i - half;
+        // frequency exp(-k * log_step): the exponent is formed in fp32 as the reference does; the
+        // exponential itself is taken in double and rounded once.
+        const float ex = -(static_cast<float>(k) * a.log_step);
+        const float freq = static_cast<float>(exp(static_cast<double>(ex)));
+        const float arg = tv * freq;
+        const float v = i < half ? sinf(arg) : cosf(arg);
+        emb[i] = v;
+        if (which == 0 && a.emb_out) a.emb_out[static_cast<int64_t>(b) * E + i] = v;
+    }
+    const bool has_label = a.n_labels > 0;
+    if (has_label) {
+        const int64_t cls = a.y[a.n_labels == 1 ? 0 : b];
+        for (int i = threadIdx.x; i < E; i += blockDim.x) lemb[i] = a.label_table[cls * E + i];
+    }
+    __syncthreads();
+    const int C = a.ch[which];
+    const float* w = a.w[which];
+    const float* bias = a.b[which];
+    const float* lw = a.lw[which];
+    const float* lb = a.lb[which];
+    float* out = a.out[which] + static_cast<int64_t>(b) * C;
+    for (int co = threadIdx.x; co < C; co += blockDim.x) {
+        const float* row = w + static_cast<int64_t>(co) * E;
+        float acc = 0.f;
+        for (int i = 0; i < 2 * half; ++i) acc += row[i] * emb[i];
+        acc += bias[co];
+        if (has_label) {
+            const float* lrow = lw + static_cast<int64_t>(co) * E;
+            float l = 0.f;
+            for (int i = 0; i < E; ++i) l += lrow[i] * lemb[i];
+            acc += l + lb[co];
+        }
+        out[co] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void sinusoidal_kernel(const void* t, int t_is_float, int batch, int E, float log_step,
+                                                          float* __restrict__ out) {
+    const int half = E >> 1;
+    const int64_t total = static_cast<int64_t>(batch) * 2 * half;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int i = static_cast<int>(idx % (2 * half));
+        const int b = static_cast<int>(idx / (2 * half));
+        const float tv = t_is_float ? static_cast<const float*>(t)[b] : static_cast<float>(static_cast<const int64_t*>(t)[b]);
+        const int k = i < half ? i : i - half;
+        const float ex = -(static_cast<float>(k) * log_step);
+        const float arg = tv * static_cast<float>(exp(static_cast<double>(ex)));
+        out[idx] = i < half ? sinf(arg) : cosf(arg);
+    }
+}
+
+static float log_step_for(int emb_dim) {
+    volatile float lg = std::log(10000.0f);
+    return lg / static_cast<float>(emb_dim / 2 - 1);
+}
+
+}  // namespace
+
+extern "C" int ddpm_sinusoidal_embedding(const void* t, int t_is_float, int batch, int emb_dim, float* out, void* stream) {
+    DDPM_REQUIRE(t && out && batch > 0 && emb_dim >= 4);
+    const int64_t total = static_cast<int64_t>(batch) * (emb_dim / 2) * 2;
+    const int grid = static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    sinusoidal_kernel<<<grid, 256, 0, ddpm::as_stream(stream)>>>(t, t_is_float, batch, emb_dim, log_step_for(emb_dim), out);
+    return ddpm::check_launch("sinusoidal_kernel");
+}
+
+extern "C" int ddpm_time_embed(const ddpm_embed_args* a, void* stream) {
+    DDPM_REQUIRE(a && a->batch > 0 && a->t);
+    DDPM_REQUIRE(a->emb_dim >= 4 && (a->emb_dim & 1) == 0 && a->emb_dim <= kMaxEmb);
+    DDPM_REQUIRE(a->n_labels == 0 || a->n_labels == 1 || a->n_labels == a->batch);
+    EmbedDev d;
+    d.batch = a->batch;
+    d.emb_dim = a->emb_dim;
+    d.n_labels = a->n_labels;
+    d.t_is_float = a->t_is_float;
+    d.t = a->t;
+    d.y = a->y;
+    d.label_table = a->label_table;
+    d.emb_out = a->emb_out;
+    for (int k = 0; k < 4; ++k) {
+        DDPM_REQUIRE(a->ch[k] > 0 && a->w[k] && a->b[k] && a->out[k]);
+        DDPM_REQUIRE(a->n_labels == 0 || (a->lw[k] && a->lb[k] && a->y && a->label_table));
+        d.ch[k] = a->ch[k];
+        d.w[k] = a->w[k];
+        d.b[k] = a->b[k];
+        d.lw[k] = a->lw[k];
+        d.lb[k] = a->lb[k];
+        d.out[k] = a->out[k];
+    }
+    d.log_step = log_step_for(a->emb_dim);
+    time_embed_kernel<<<dim3(a->batch, 4), 256, 0, ddpm::as_stream(stream)>>>(d);
+    return ddpm::check_launch("time_embed_kernel");
+}

@@ -1,0 +1,4 @@
+"""Drop-in for second-iteration/diffusion.py."""
+from _ddpm_amd import ITERATION, pkg
+
+DiffusionModel = pkg.make_diffusion_class(ITERATION)

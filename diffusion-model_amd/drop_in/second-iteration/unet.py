@@ -1,0 +1,4 @@
+"""Drop-in for second-iteration/unet.py: same class, constructor arguments and state_dict keys."""
+from _ddpm_amd import ITERATION, pkg
+
+UNet = pkg.make_unet_class(ITERATION)

@@ -1,0 +1,4 @@
+"""Drop-in for third-iteration/beta_scheduler.py."""
+from _ddpm_amd import pkg
+
+BetaScheduler = pkg.BetaScheduler

@@ -1,0 +1,343 @@
+"""Schedule of HIP kernels that evaluates the three UNet variants (and their backward pass).
+
+The nn.Module in unet_impl.py only holds parameters under the reference's state_dict names; all
+arithmetic happens here, as an explicit list of calls into libddpm_mi355x.so on raw device
+pointers. Activations are NHWC fp32 (torch channels_last memory), allocated through torch's
+caching allocator; kernels run on torch's current stream.
+
+Reference behaviour this schedule reproduces: first-iteration/unet.py:75-115,
+second-iteration/unet.py:118-158, third-iteration/unet.py:126-178.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, EmbedArgs, Epilogue, call
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+BN_EPS = 1e-5
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class View:
+    """A channel slice [c0, c0+c) of an NHWC buffer `buf` of shape [B, H, W, ld]."""
+
+    __slots__ = ("buf", "c0", "c")
+
+    def __init__(self, buf, c0=0, c=None):
+        self.buf, self.c0 = buf, c0
+        self.c = buf.shape[-1] - c0 if c is None else c
+
+    @property
+    def ld(self):
+        return self.buf.shape[-1]
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.buf.data_ptr() + 4 * self.c0)
+
+    @property
+    def bhw(self):
+        return self.buf.shape[0], self.buf.shape[1], self.buf.shape[2]
+
+    def nchw(self):
+        """Logical [B, C, H, W] tensor sharing this memory (channels_last strides)."""
+        return self.buf[..., self.c0:self.c0 + self.c].permute(0, 3, 1, 2)
+
+
+class UNetEngine:
+    def __init__(self, module, variant, in_channels, out_channels, base_channels, embedding_dim, num_classes):
+        if base_channels % 4 != 0:
+            raise NotImplementedError("base_channels must be a multiple of 4 for the 16-byte vector paths")
+        if embedding_dim % 2 != 0 or embedding_dim < 4:
+            raise NotImplementedError("embedding_dim must be even and >= 4")
+        self.m = module
+        self.v = variant
+        self.cin, self.cout_final = in_channels, out_channels
+        self.base, self.emb = base_channels, embedding_dim
+        self.num_classes = num_classes
+        self._cache = {}
+        self._tensors = None
+
+    # ------------------------------------------------------------------ entry point
+    def invalidate(self):
+        """Parameters were moved or replaced (module._apply): drop every derived cache."""
+        self._cache.clear()
+        self._tensors = None
+
+    def run(self, x, t, y, training):
+        if x.dtype != torch.float32:
+            x = x.float()
+        t = t.to(x.device)
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.m.parameters()))
+        if needs_grad or training:
+            raise NotImplementedError("train-mode / differentiable forward is not wired up yet")
+        return self.forward_eval(x, t, y)
+
+    # ------------------------------------------------------------------ parameters and caches
+    def T(self, key):
+        if self._tensors is None:
+            d = dict(self.m.named_parameters())
+            d.update(dict(self.m.named_buffers()))
+            self._tensors = d
+        return self._tensors[key]
+
+    def _cached(self, kind, keys, build):
+        ts = [self.T(k) for k in keys]
+        stamp = tuple((t._version, t.data_ptr()) for t in ts)
+        hit = self._cache.get((kind, keys[0]))
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        with torch.no_grad():
+            val = build(*ts)
+        self._cache[(kind, keys[0])] = (stamp, val)
+        return val
+
+    def packed_conv3(self, key, flip=False):
+        def build(w):
+            out = torch.empty(9 * w.shape[0] * w.shape[1], device=w.device, dtype=torch.float32)
+            call("ddpm_pack_conv3x3", _ptr(w.detach().contiguous()), w.shape[0], w.shape[1], int(flip), _ptr(out), _stream())
+            return out
+        return self._cached("pk3f" if flip else "pk3", (key + ".weight",), build)
+
+    def packed_convT(self, key):
+        def build(w):
+            out = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+            call("ddpm_pack_convT2x2", _ptr(w.detach().contiguous()), w.shape[0], w.shape[1], _ptr(out), _stream())
+            return out
+        return self._cached("pkT", (key + ".weight",), build)
+
+    def folded_bn(self, conv_key, bn_key):
+        """Eval-mode BatchNorm folded with the conv bias: y = conv*scale + shift."""
+        def build(cb, w, b, rm, rv):
+            scale = w / torch.sqrt(rv + BN_EPS)
+            shift = (cb - rm) * scale + b
+            return scale.contiguous(), shift.contiguous()
+        keys = (conv_key + ".bias", bn_key + ".weight", bn_key + ".bias", bn_key + ".running_mean", bn_key + ".running_var")
+        return self._cached("fold", keys, build)
+
+    def packed_qkv(self, key):
+        """[2*dqp + C][C] weight and [2*dqp + C] bias; q and k zero-padded to dqp = round_up(C/8, 8) rows."""
+        def build(qw, qb, kw, kb, vw, vb):
+            c = vw.shape[0]
+            dq = qw.shape[0]
+            dqp = _round_up(dq, 8)
+            w = torch.zeros(2 * dqp + c, c, device=vw.device, dtype=torch.float32)
+            b = torch.zeros(2 * dqp + c, device=vw.device, dtype=torch.float32)
+            w[:dq] = qw.reshape(dq, c)
+            w[dqp:dqp + dq] = kw.reshape(dq, c)
+            w[2 * dqp:] = vw.reshape(c, c)
+            b[:dq], b[dqp:dqp + dq], b[2 * dqp:] = qb, kb, vb
+            return w, b, dqp
+        keys = tuple(f"{key}.{n}.{s}" for n in ("query", "key", "value") for s in ("weight", "bias"))
+        return self._cached("qkv", keys, build)
+
+    # ------------------------------------------------------------------ kernel wrappers
+    @staticmethod
+    def _new(b, h, w, c, like):
+        return torch.empty((b, h, w, c), device=like.device, dtype=torch.float32)
+
+    def conv3x3(self, src, wkey_packed, cout, out, scale=None, shift=None, residual=None, temb=None, act=ACT_NONE):
+        b, h, w = src.bhw
+        d = ConvDesc(batch=b, in_h=h, in_w=w, c1=src.c, ld1=src.ld, c2=0, ld2=0, cout=cout, ldo=out.ld, act=act,
+                     ldr=residual.ld if residual is not None else 0, out_h=h, out_w=w, off_y=0, off_x=0)
+        ep = Epilogue(_ptr(scale), _ptr(shift), residual.ptr if residual is not None else None, _ptr(temb))
+        call("ddpm_conv3x3_fwd", C.byref(d), src.ptr, None, _ptr(wkey_packed), C.byref(ep), out.ptr, _stream())
+
+    def conv1x1(self, src, w, bias, cout, out):
+        b, h, wd = src.bhw
+        d = ConvDesc(batch=b, in_h=h, in_w=wd, c1=src.c, ld1=src.ld, c2=0, ld2=0, cout=cout, ldo=out.ld, act=ACT_NONE,
+                     ldr=0, out_h=h, out_w=wd, off_y=0, off_x=0)
+        ep = Epilogue(None, _ptr(bias), None, None)
+        call("ddpm_conv1x1_fwd", C.byref(d), src.ptr, None, _ptr(w), C.byref(ep), out.ptr, _stream())
+
+    def convT(self, src, key, out):
+        """ConvTranspose2d(k=2,s=2) of `src`, padded/cropped (centre, floor-division offsets) into `out`."""
+        b, h, w = src.bhw
+        _, oh, ow = out.bhw
+        dy, dx = oh - 2 * h, ow - 2 * w
+        off_y, off_x = dy // 2, dx // 2            # python floor division, also for negatives
+        if dy > 0 or dx > 0:                       # positive padding leaves a zero border
+            out.buf[..., out.c0:out.c0 + out.c].zero_()
+        cout = out.c
+        d = ConvDesc(batch=b, in_h=h, in_w=w, c1=src.c, ld1=src.ld, c2=0, ld2=0, cout=cout, ldo=out.ld, act=ACT_NONE,
+                     ldr=0, out_h=oh, out_w=ow, off_y=off_y, off_x=off_x)
+        ep = Epilogue(None, _ptr(self.T(key + ".bias")), None, None)
+        call("ddpm_convT2x2_fwd", C.byref(d), src.ptr, _ptr(self.packed_convT(key)), C.byref(ep), out.ptr, _stream())
+
+    def pool_skip(self, x, temb, skip, pooled):
+        b, h, w = x.bhw
+        call("ddpm_pool_skip_fwd", x.ptr, x.ld, _ptr(temb), skip.ptr if skip is not None else None,
+             skip.ld if skip is not None else 0, pooled.ptr if pooled is not None else None,
+             pooled.ld if pooled is not None else 0, None, b, h, w, x.c, _stream())
+
+    def add_temb(self, x, temb, out):
+        b, h, w = x.bhw
+        call("ddpm_add_temb", x.ptr, x.ld, _ptr(temb), out.ptr, out.ld, b, h * w, x.c, _stream())
+
+    def time_embed(self, t, y):
+        B = t.shape[0]
+        dev = t.device
+        chans = [self.base, self.base * 2, self.base * 4, self.base * 8]
+        outs = [torch.empty((B, c), device=dev, dtype=torch.float32) for c in chans]
+        a = EmbedArgs()
+        a.batch, a.emb_dim = B, self.emb
+        if t.dtype == torch.int64:
+            a.t_is_float = 0
+        elif t.dtype == torch.float32:
+            a.t_is_float = 1
+        else:
+            t = t.to(torch.int64)
+            a.t_is_float = 0
+        t = t.contiguous()
+        a.t = t.data_ptr()
+        keep = [t]
+        if y is not None:
+            if self.num_classes is None:
+                raise AttributeError("this UNet was built without num_classes; it has no label embedding")
+            y = y.to(device=dev, dtype=torch.int64).contiguous()
+            if y.numel() not in (1, B):
+                raise RuntimeError(f"label tensor of {y.numel()} entries cannot broadcast over a batch of {B}")
+            keep.append(y)
+            a.n_labels = y.numel()
+            a.y = y.data_ptr()
+            a.label_table = self.T("label_embedding.weight").data_ptr()
+        else:
+            a.n_labels = 0
+        for k in range(4):
+            a.ch[k] = chans[k]
+            a.w[k] = self.T(f"time_fc{k + 1}.weight").data_ptr()
+            a.b[k] = self.T(f"time_fc{k + 1}.bias").data_ptr()
+            if y is not None:
+                a.lw[k] = self.T(f"label_emdedding_fc{k + 1}.weight").data_ptr()
+                a.lb[k] = self.T(f"label_emdedding_fc{k + 1}.bias").data_ptr()
+            a.out[k] = outs[k].data_ptr()
+        a.emb_out = None
+        call("ddpm_time_embed", C.byref(a), _stream())
+        return outs
+
+    # ------------------------------------------------------------------ blocks (eval mode)
+    def _act(self):
+        return ACT_RELU if self.v == 1 else ACT_GELU
+
+    def double_conv_eval(self, src, key, cout, out, temb=None, first=None):
+        """DoubleConv with BatchNorm folded into the conv epilogues. `first` = NCHW image for enc1."""
+        p = key + ".double_conv"
+        b, h, w = out.bhw
+        act = self._act()
+        s0, h0 = self.folded_bn(p + ".0", p + ".1")
+        a = View(self._new(b, h, w, cout, out.buf))
+        if first is not None:
+            ep = Epilogue(_ptr(s0), _ptr(h0), None, None)
+            wt = self.T(p + ".0.weight")
+            call("ddpm_conv3x3_first_fwd", _ptr(first), _ptr(wt), C.byref(ep), act, a.ptr, b, first.shape[1], h, w, cout,
+                 a.ld, _stream())
+        else:
+            self.conv3x3(src, self.packed_conv3(p + ".0"), cout, a, s0, h0, act=act)
+        if self.v == 1:
+            s1, h1 = self.folded_bn(p + ".3", p + ".4")
+            self.conv3x3(a, self.packed_conv3(p + ".3"), cout, out, s1, h1, temb=temb, act=act)
+            return
+        r = p + ".3.conv_block"
+        s1, h1 = self.folded_bn(r + ".0", r + ".1")
+        s2, h2 = self.folded_bn(r + ".3", r + ".4")
+        m = View(self._new(b, h, w, cout, out.buf))
+        self.conv3x3(a, self.packed_conv3(r + ".0"), cout, m, s1, h1, act=act)
+        self.conv3x3(m, self.packed_conv3(r + ".3"), cout, out, s2, h2, residual=a, temb=temb, act=act)
+
+    def attention(self, x, key, out, temb=None, save=None):
+        b, h, w = x.bhw
+        c = x.c
+        wq, bq, dqp = self.packed_qkv(key)
+        if dqp not in (8, 16, 32, 64):
+            raise NotImplementedError(f"attention with C/8 = {c // 8} query channels is not supported")
+        qkv = View(self._new(b, h, w, 2 * dqp + c, x.buf))
+        self.conv1x1(x, wq, bq, 2 * dqp + c, qkv)
+        raw = lse = None
+        if save is not None:
+            raw = torch.empty((b, h, w, c), device=x.buf.device, dtype=torch.float32)
+            lse = torch.empty((b, h * w), device=x.buf.device, dtype=torch.float32)
+            save.update(qkv=qkv, raw=raw, lse=lse)
+        call("ddpm_attention_fwd", qkv.ptr, x.ptr, x.ld, _ptr(self.T(key + ".gamma")), out.ptr, out.ld, _ptr(raw), _ptr(lse),
+             _ptr(temb), b, h * w, c, dqp, _stream())
+
+    # ------------------------------------------------------------------ whole network, eval mode
+    def forward_eval(self, x, t, y=None, want_fms=True):
+        B, cin, H, W = x.shape
+        if cin != self.cin:
+            raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
+        x = x.contiguous()
+        dev = x.device
+        bc = self.base
+        v1 = self.v == 1
+        temb = self.time_embed(t, y)
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        fms = []
+
+        def buf(h, w, c):
+            return torch.empty((B, h, w, c), device=dev, dtype=torch.float32)
+
+        # concatenation buffers [skip | upsampled] of the three UpBlocks
+        cat3, cat2, cat1 = buf(H, W, 2 * bc), buf(H, W, 4 * bc), buf(H2, W2, 8 * bc)
+        skip1, skip2, skip3 = View(cat3, 0, bc), View(cat2, 0, 2 * bc), View(cat1, 0, 4 * bc)
+
+        # enc1: the skip (with embedding) is also the input of enc2
+        self.double_conv_eval(None, "enc1", bc, skip1, temb=temb[0], first=x)
+        fms.append(skip1)
+
+        def down(src, key, cout, skip, te, h, w):
+            xfull = View(buf(h, w, cout))
+            self.double_conv_eval(src, key + ".conv", cout, xfull)
+            if not v1:
+                xa = View(buf(h, w, cout))
+                self.attention(xfull, key + ".attention", xa)
+                xfull = xa
+            pooled = View(buf(h // 2, w // 2, cout))
+            self.pool_skip(xfull, te, skip, pooled)      # pooled copy carries no embedding
+            return pooled
+
+        p2 = down(skip1, "enc2", 2 * bc, skip2, temb[1], H, W)
+        fms.append(skip2)
+        p3 = down(p2, "enc3", 4 * bc, skip3, temb[2], H2, W2)
+        fms.append(skip3)
+
+        def tail(src, key_conv, key_attn, cout, te, h, w):
+            """DoubleConv (+attention) + embedding add; returns the tensor handed to the next block."""
+            if v1:
+                pre = View(buf(h, w, cout))
+                self.double_conv_eval(src, key_conv, cout, pre)
+                fms.append(pre)                           # v1 records before the embedding add
+                post = View(buf(h, w, cout))
+                self.add_temb(pre, te, post)
+                return post
+            mid = View(buf(h, w, cout))
+            self.double_conv_eval(src, key_conv, cout, mid)
+            post = View(buf(h, w, cout))
+            self.attention(mid, key_attn, post, temb=te)
+            fms.append(post)
+            return post
+
+        hcur = tail(p3, "bottleneck" if v1 else "bottleneck.0", "bottleneck.1", 8 * bc, temb[3], H4, W4)
+        for key, cat, cskip, cout, te, (h, w) in (("dec1", cat1, 4 * bc, 4 * bc, temb[2], (H2, W2)),
+                                                   ("dec2", cat2, 2 * bc, 2 * bc, temb[1], (H, W)),
+                                                   ("dec3", cat3, bc, bc, temb[0], (H, W))):
+            self.convT(hcur, key + ".up", View(cat, cskip, cskip))
+            hcur = tail(View(cat), key + ".conv", key + ".attention", cout, te, h, w)
+
+        out = torch.empty((B, self.cout_final, H, W), device=dev, dtype=torch.float32)
+        fw = self.T("final_conv.weight")
+        call("ddpm_conv1x1_final_fwd", hcur.ptr, hcur.ld, _ptr(fw), _ptr(self.T("final_conv.bias")), _ptr(out), B, H, W, bc,
+             self.cout_final, _stream())
+        return out, ([f.nchw() for f in fms] if want_fms else [])

@@ -1,0 +1,219 @@
+/*
+ * ddpm_mi355x.h -- C ABI of libddpm_mi355x.so: the DDPM hot path of vemunderoe/diffusion-model
+ * as hand-written gfx950 (MI355X) kernels.
+ *
+ * The reference has no FFI; its boundary for this path is the Python module surface
+ * (unet.UNet, diffusion.DiffusionModel, beta_scheduler.BetaScheduler,
+ * embeddings.SinusoidalTimeEmbedding). The drop-in modules shipped next to this library keep
+ * that surface and bind the entry points below with ctypes. Every entry point cites the
+ * reference code it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - All device pointers are BORROWED (owned by the caller, e.g. torch tensors). The library
+ *    never allocates, frees or synchronises; every kernel is enqueued on the `stream` argument
+ *    (a hipStream_t passed as void*), so HIP-graph capture and multi-stream overlap work.
+ *  - Activations are fp32 "NHWC": element (b, y, x, c) of a tensor with C channels lives at
+ *    ((b*H + y)*W + x)*ld + c, where the pixel stride `ld` >= C lets a tensor be a channel
+ *    slice of a wider buffer (the skip/upsample concatenation is never materialised twice).
+ *    This is the memory image of a torch channels_last tensor of logical shape [B,C,H,W].
+ *  - Return value: 0 on success, a negative DDPM_E_* code on failure; ddpm_last_error() gives
+ *    a thread-local message. Nothing throws across the boundary. Shapes are validated on the
+ *    host BEFORE any launch.
+ *  - One device per call: the device that is current on the calling thread.
+ */
+#ifndef DDPM_MI355X_H
+#define DDPM_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDPM_OK 0
+#define DDPM_E_INVALID (-1)  /* bad argument / unsupported shape */
+#define DDPM_E_LAUNCH (-2)   /* HIP reported an error at launch   */
+
+#define DDPM_ACT_NONE 0
+#define DDPM_ACT_RELU 1 /* first-iteration/unet.py:18,21 */
+#define DDPM_ACT_GELU 2 /* exact erf GELU, second-iteration/unet.py:19,26,35 */
+
+const char* ddpm_last_error(void);
+int ddpm_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Host-side tables (no GPU work).
+ * ------------------------------------------------------------------------------------- */
+
+/* beta schedule, float64 math rounded once to fp32. kind: 0 linear, 1 quadratic, 2 cosine.
+ * Replaces BetaScheduler.linear/quadratic/cosine, first-iteration/beta_scheduler.py:12-26.
+ * betas: host array [timesteps]. */
+int ddpm_schedule_betas(int kind, int timesteps, double beta_start, double beta_end, float* betas);
+
+/* alphas = 1 - betas (fp32); alpha_bar = running product accumulated in float64 and rounded to
+ * fp32 per element (what torch.cumprod does on CPU). Replaces DiffusionModel.__init__,
+ * first-iteration/diffusion.py:9-10. Host arrays [timesteps]. */
+int ddpm_schedule_tables(int timesteps, const float* betas, float* alphas, float* alpha_bar);
+
+/* c[0] = 1/sqrt(alpha_t), c[1] = (1-alpha_t)/sqrt(1-alpha_bar_t), c[2] = sqrt(beta_t); every
+ * operation a correctly rounded fp32 op. Replaces the 0-dim tensor arithmetic of
+ * first-iteration/diffusion.py:26-28,36-37. */
+int ddpm_step_coefficients(float beta_t, float alpha_t, float alpha_bar_t, float c[3]);
+
+/* ---------------------------------------------------------------------------------------
+ * Elementwise process kernels (HBM-bound).
+ * ------------------------------------------------------------------------------------- */
+
+/* x_out = c1*(x - c2*eps) + c3*z, five separately rounded fp32 ops (no FMA contraction), n
+ * elements. z == NULL means the t == 0 step (no noise term; the reference adds sqrt(beta)*0).
+ * eps_uncond != NULL applies classifier-free guidance first:
+ * eps = lerp(eps_uncond, eps, cfg_w) with torch.lerp's two-branch formula.
+ * Replaces first-iteration/diffusion.py:30-37 and third-iteration/diffusion.py:29-31,42-44.
+ * x_out may alias x. 16 B per element algorithmic traffic (12 B when z == NULL). */
+int ddpm_reverse_step(const float* x, const float* eps, const float* eps_uncond, float cfg_w,
+                      const float* z, float c1, float c2, float c3, float* x_out, int64_t n,
+                      void* stream);
+
+/* out[b,:] = sqrt(abar[t[b]])*x0[b,:] + sqrt(1-abar[t[b]])*noise[b,:]; t: device int64 [batch],
+ * alpha_bar: device fp32 [timesteps]; per_sample = C*H*W elements.
+ * Replaces DiffusionModel.add_noise, first-iteration/diffusion.py:12-15. */
+int ddpm_add_noise(const float* x0, const float* noise, const int64_t* t, const float* alpha_bar,
+                   int timesteps, float* out, int batch, int64_t per_sample, void* stream);
+
+/* loss = mean((pred-target)^2) over n elements -> loss_out[0] (device). partial: device scratch
+ * of ddpm_mse_partial_count() doubles. Replaces nn.MSELoss() forward, first-iteration/main.py:48,79. */
+int ddpm_mse_partial_count(void);
+int ddpm_mse_fwd(const float* pred, const float* target, int64_t n, double* partial, float* loss_out,
+                 void* stream);
+/* grad[i] = gout[0] * 2*(pred[i]-target[i])/n   (gout: device scalar = d loss). */
+int ddpm_mse_bwd(const float* pred, const float* target, const float* gout, int64_t n, float* grad,
+                 void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Time / label embedding: sinusoidal embedding followed by the four time Linears (and, when
+ * labels are given, the label Embedding + four label Linears added on top).
+ * Replaces SinusoidalTimeEmbedding.forward (first-iteration/embeddings.py:11-20), the time_fc
+ * calls of first-iteration/unet.py:78-82 and third-iteration/unet.py:135-145.
+ * ------------------------------------------------------------------------------------- */
+typedef struct ddpm_embed_args {
+    int32_t batch;          /* B */
+    int32_t emb_dim;        /* E (even, >= 4) */
+    int32_t n_labels;       /* 0 = unconditional; 1 = one label broadcast over the batch; else B */
+    int32_t t_is_float;     /* timesteps are fp32 instead of int64 */
+    const void* t;          /* device [B] int64 (or fp32) */
+    const int64_t* y;       /* device [n_labels] or NULL */
+    const float* label_table; /* device [num_classes][E] or NULL */
+    int32_t ch[4];          /* output widths C1..C4 */
+    const float* w[4];      /* time Linear weights [Ck][E] */
+    const float* b[4];      /* time Linear biases  [Ck]    */
+    const float* lw[4];     /* label Linear weights (or NULL) */
+    const float* lb[4];
+    float* out[4];          /* device [B][Ck] */
+    float* emb_out;         /* optional device [B][E]: the sinusoidal embedding itself (or NULL) */
+} ddpm_embed_args;
+int ddpm_time_embed(const ddpm_embed_args* a, void* stream);
+
+/* The sinusoidal embedding alone: out[b] = [sin(t_b*f_k) | cos(t_b*f_k)], f_k = exp(-k*ln(1e4)/(E/2-1)),
+ * written as [batch][2*(E/2)]. Replaces SinusoidalTimeEmbedding.forward, first-iteration/embeddings.py:11-20. */
+int ddpm_sinusoidal_embedding(const void* t, int t_is_float, int batch, int emb_dim, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Convolutions as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32), LDS-staged tiles.
+ * rows = pixels, columns = output channels, K = taps * input channels.
+ * ------------------------------------------------------------------------------------- */
+typedef struct ddpm_conv_desc {
+    int32_t batch, in_h, in_w;       /* input geometry */
+    int32_t c1, ld1;                 /* channels read from src1 and its pixel stride (floats) */
+    int32_t c2, ld2;                 /* channels read from src2 (0 = single source): the channel
+                                        concatenation [src1 | src2] of UpBlock, never materialised */
+    int32_t cout;                    /* output channels */
+    int32_t ldo;                     /* pixel stride of the output */
+    int32_t act;                     /* DDPM_ACT_* applied after scale/shift (+residual) */
+    int32_t ldr;                     /* pixel stride of the residual tensor */
+    /* transposed conv only: output geometry and placement of the un-padded 2H x 2W result in it
+     * (negative offsets crop, positive offsets leave a zero border the caller has cleared). */
+    int32_t out_h, out_w, off_y, off_x;
+} ddpm_conv_desc;
+
+/* Epilogue applied to every output element v (column n = output channel, pixel p, sample b):
+ *   v = scale ? v*scale[n] + shift[n] : (shift ? v + shift[n] : v)   -- bias or folded BatchNorm
+ *   v = residual ? v + residual[p*ldr + n] : v
+ *   v = act(v)
+ *   v = temb ? v + temb[b*cout + n] : v
+ */
+typedef struct ddpm_epilogue {
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    const float* temb;
+} ddpm_epilogue;
+
+/* 3x3, padding 1, stride 1. w_packed: [9][cout][c1+c2] (see ddpm_pack_conv3x3).
+ * Replaces nn.Conv2d(k=3,p=1) (+ eval BatchNorm2d + ReLU/GELU + residual + time-embedding add):
+ * first-iteration/unet.py:16-21, second-iteration/unet.py:16-21,26,32-36.
+ * Requires c1 % 4 == c2 % 4 == ld % 4 == 0. */
+int ddpm_conv3x3_fwd(const ddpm_conv_desc* d, const float* src1, const float* src2,
+                     const float* w_packed, const ddpm_epilogue* ep, float* out, void* stream);
+
+/* 1x1. w_packed: [cout][c1+c2]. Replaces the query/key/value projections
+ * (second-iteration/unet.py:45-47,52-57) as ONE GEMM with cout = 2*(C/8) + C. */
+int ddpm_conv1x1_fwd(const ddpm_conv_desc* d, const float* src1, const float* src2,
+                     const float* w_packed, const ddpm_epilogue* ep, float* out, void* stream);
+
+/* ConvTranspose2d(k=2, s=2) followed by F.pad/crop to (out_h, out_w): output pixel
+ * (2y+a+off_y, 2x+b+off_x), dropped when outside. w_packed: [4*cout][c1] with row
+ * (a*2+b)*cout + co; shift = bias[co] (length cout). Only input pixels whose outputs survive the
+ * crop are computed. Replaces first-iteration/unet.py:41,45-48. */
+int ddpm_convT2x2_fwd(const ddpm_conv_desc* d, const float* src, const float* w_packed,
+                      const ddpm_epilogue* ep, float* out, void* stream);
+
+/* Weight repacking (device -> device), torch layouts in:
+ *   conv3x3: [cout][cin][3][3] -> [9][cout][cin]; flip=1 additionally swaps the roles for the
+ *            data-gradient conv: out[tap'][ci][co] = w[co][ci][8-tap'] (a 3x3 conv of dY).
+ *   convT:   [cin][cout][2][2] -> [4*cout][cin]. */
+int ddpm_pack_conv3x3(const float* w, int cout, int cin, int flip, float* out, void* stream);
+int ddpm_pack_convT2x2(const float* w, int cin, int cout, float* out, void* stream);
+
+/* First layer: 3x3 pad 1 on an NCHW input with few channels (1 or 3), direct (non-MFMA),
+ * writes NHWC with the same epilogue. w: torch layout [cout][cin][3][3].
+ * Replaces the first Conv2d of enc1, first-iteration/unet.py:61. */
+int ddpm_conv3x3_first_fwd(const float* x_nchw, const float* w, const ddpm_epilogue* ep, int act,
+                           float* out, int batch, int cin, int h, int w_, int cout, int ldo,
+                           void* stream);
+
+/* Last layer: 1x1 conv NHWC (c channels, stride ld) -> NCHW [B][cout][H][W] + bias.
+ * w: [cout][c]. Replaces final_conv, first-iteration/unet.py:71,115. */
+int ddpm_conv1x1_final_fwd(const float* x, int ld, const float* w, const float* bias, float* out_nchw,
+                           int batch, int h, int w_, int c, int cout, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Pooling + skip hand-off: skip = x + temb (full resolution), pooled = maxpool2x2(x) WITHOUT the
+ * embedding. Replaces DownBlock.pool and the `skip + time_emb` adds,
+ * first-iteration/unet.py:31,35,89-94. temb may be NULL (plain copy), pooled may be NULL
+ * (add only), argmax (uint8 per pooled element, 0..3 = dy*2+dx) may be NULL.
+ * ------------------------------------------------------------------------------------- */
+int ddpm_pool_skip_fwd(const float* x, int ldx, const float* temb, float* skip, int lds, float* pooled,
+                       int ldp, uint8_t* argmax, int batch, int h, int w, int c, void* stream);
+
+/* y = x + temb[b][c] (broadcast over pixels); y may alias x. first-iteration/unet.py:100,105,109,113. */
+int ddpm_add_temb(const float* x, int ldx, const float* temb, float* y, int ldy, int batch, int hw,
+                  int c, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Self-attention, single head, unscaled, d_qk = C/8, d_v = C, flash-style (the N x N matrix is
+ * never materialised): out = gamma * softmax(Q K^T) V + x.
+ * qkv: [B][N][2*dq + C] (q | k | v per pixel, from ddpm_conv1x1_fwd), x/out: [B][N][C].
+ * gamma: device scalar. Optional outputs for the backward pass: attn_raw [B][N][C] (the attention
+ * output before the gate) and lse [B][N] (log-sum-exp of every score row). temb (optional,
+ * [B][C]) is added after the gate: the `x + time_emb` that follows every attention block outside
+ * the encoder. Replaces SelfAttention.forward, second-iteration/unet.py:50-61 (+ :142,147,151,155).
+ * ------------------------------------------------------------------------------------- */
+int ddpm_attention_fwd(const float* qkv, const float* x, int ldx, const float* gamma, float* out,
+                       int ldo, float* attn_raw, float* lse, const float* temb, int batch, int n, int c,
+                       int dq, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDPM_MI355X_H */

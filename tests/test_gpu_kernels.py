@@ -1,0 +1,293 @@
+"""Per-kernel parity on the GPU, through the C ABI, against the CPU oracle / torch fp32 on CPU.
+
+Tolerances: elementwise process kernels are bit-exact; MFMA contractions are fp32 with a
+different summation order than the CPU, so they are held to 2e-5 of the tensor's scale
+(K up to 9*512 products per output).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from gpu_util import ConvDesc, Epilogue, P, assert_close, call, from_nhwc, rnd, stream, to_nhwc
+from oracle import ddpm_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+# ---------------------------------------------------------------- elementwise, bit-exact
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_reverse_step_bit_exact_golden(tag):
+    g = load_golden("elementwise.npz")
+    x, eps, z = (torch.from_numpy(g[f"{tag}_{k}"]).cuda() for k in ("x0", "eps", "z"))
+    for tt in (999, 500, 1, 0):
+        c1, c2, c3 = (float(v) for v in g[f"{tag}_coef_t{tt}"])
+        out = torch.empty_like(x)
+        call("ddpm_reverse_step", P(x), P(eps), None, 0.0, P(z) if tt > 0 else None, c1, c2, c3, P(out), x.numel(), stream())
+        assert out.cpu().numpy().tobytes() == g[f"{tag}_step_t{tt}"].tobytes()
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 4096 * 3 + 2, 1 << 22])
+@pytest.mark.parametrize("w", [0.0, 0.25, 0.5, 2.0])
+def test_reverse_step_ragged_and_guided(n, w):
+    x, e, u, z = (rnd((n,), s) for s in (1, 2, 3, 4))
+    c1, c2, c3 = np.float32(1.0101), np.float32(0.0123), np.float32(0.1414)
+    xe, ee, ue, ze = (t.cuda() for t in (x, e, u, z))
+    out = torch.empty_like(xe)
+    call("ddpm_reverse_step", P(xe), P(ee), P(ue) if w > 0 else None, float(w), P(ze), float(c1), float(c2), float(c3), P(out), n,
+         stream())
+    eps = O.cfg_blend(u.numpy(), e.numpy(), w) if w > 0 else e.numpy()
+    want = O.reverse_step(x.numpy(), eps, z.numpy(), c1, c2, c3)
+    assert out.cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_cfg_blend_golden():
+    g = load_golden("elementwise.npz")
+    u, c = torch.from_numpy(g["cfg_u"]).cuda(), torch.from_numpy(g["cfg_c"]).cuda()
+    x = torch.zeros_like(u)
+    for w in (0.25, 0.5, 2.0):
+        out = torch.empty_like(u)
+        # x = 0, c1 = 1, c2 = -1... use c2 = 1 and negate: out = 0 - 1*eps -> compare -out with lerp
+        call("ddpm_reverse_step", P(x), P(c), P(u), float(w), None, 1.0, 1.0, 0.0, P(out), u.numel(), stream())
+        assert np.array_equal(-out.cpu().numpy(), g[f"cfg_w{w}"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_add_noise(tag):
+    g = load_golden("elementwise.npz")
+    betas = O.schedule_betas("linear", 1000)
+    _, abar = O.schedule_tables(betas)
+    x0, eps = torch.from_numpy(g[f"{tag}_x0"]).cuda(), torch.from_numpy(g[f"{tag}_eps"]).cuda()
+    t = torch.from_numpy(g[f"{tag}_t"]).cuda()
+    out = torch.empty_like(x0)
+    call("ddpm_add_noise", P(x0), P(eps), P(t), P(torch.from_numpy(abar).cuda()), 1000, P(out), x0.shape[0],
+         x0.numel() // x0.shape[0], stream())
+    want = O.add_noise(g[f"{tag}_x0"], g[f"{tag}_eps"], g[f"{tag}_t"], abar)
+    assert out.cpu().numpy().tobytes() == want.tobytes()                        # bit-exact vs the IEEE oracle
+    np.testing.assert_allclose(out.cpu().numpy(), g[f"{tag}_noisy"], rtol=3e-7, atol=1e-7)   # reference: torch sqrt, 1 ulp
+
+
+def test_add_noise_ragged_sample_size():
+    betas = O.schedule_betas("cosine", 100)
+    _, abar = O.schedule_tables(betas)
+    x0, eps = rnd((5, 3, 7, 5), 1), rnd((5, 3, 7, 5), 2)
+    t = torch.tensor([0, 99, 50, 1, 98])
+    out = torch.empty((5, 3, 7, 5), device="cuda")
+    call("ddpm_add_noise", P(x0.cuda()), P(eps.cuda()), P(t.cuda()), P(torch.from_numpy(abar).cuda()), 100, P(out), 5, 105, stream())
+    assert out.cpu().numpy().tobytes() == O.add_noise(x0.numpy(), eps.numpy(), t.numpy(), abar).tobytes()
+
+
+def test_mse_fwd_bwd():
+    n = 3 * 1 * 28 * 28 + 5
+    p, y = rnd((n,), 1), rnd((n,), 2)
+    pc, yc = p.cuda(), y.cuda()
+    part = torch.empty(1024, dtype=torch.float64, device="cuda")
+    loss = torch.empty(1, device="cuda")
+    call("ddpm_mse_fwd", P(pc), P(yc), n, P(part), P(loss), stream())
+    want = F.mse_loss(p.double(), y.double())
+    assert abs(loss.item() - want.item()) <= 1e-6 * want.item()
+    gout = torch.tensor([0.7], device="cuda")
+    grad = torch.empty_like(pc)
+    call("ddpm_mse_bwd", P(pc), P(yc), P(gout), n, P(grad), stream())
+    assert_close(grad.cpu(), 0.7 * 2 * (p - y) / n, 1e-6, "mse grad")
+
+
+# ---------------------------------------------------------------- embedding
+def test_sinusoidal_embedding_and_linears():
+    g = load_golden("embeddings.npz")
+    t = torch.arange(1000).cuda()
+    out = torch.empty((1000, 128), device="cuda")
+    call("ddpm_sinusoidal_embedding", P(t), 0, 1000, 128, P(out), stream())
+    # E=128: the frequency table matches the reference bit for bit; sin/cos implementations differ by <= 2 ulp
+    np.testing.assert_allclose(out.cpu().numpy(), g["E128_t0_999"], rtol=0, atol=5e-7)
+    few = torch.from_numpy(g["t_few"]).cuda()
+    for dim in (16, 64, 256):
+        o = torch.empty((4, dim), device="cuda")
+        call("ddpm_sinusoidal_embedding", P(few), 0, 4, dim, P(o), stream())
+        # a 1-ulp frequency difference is amplified by t <= 999 before sin/cos
+        np.testing.assert_allclose(o.cpu().numpy(), g[f"E{dim}_few"], rtol=0, atol=1.5e-4)
+    o = torch.empty((4, 128), device="cuda")
+    call("ddpm_sinusoidal_embedding", P(few.float()), 1, 4, 128, P(o), stream())
+    np.testing.assert_allclose(o.cpu().numpy(), g["E128_float_few"], rtol=0, atol=5e-7)
+
+
+# ---------------------------------------------------------------- convolutions
+def conv_ref(x, w, b, scale, shift, res, temb, act):
+    y = F.conv2d(x, w, None, padding=w.shape[-1] // 2)
+    if scale is not None:
+        y = y * scale[None, :, None, None] + shift[None, :, None, None]
+    elif shift is not None:
+        y = y + shift[None, :, None, None]
+    if res is not None:
+        y = y + res
+    y = F.relu(y) if act == 1 else (F.gelu(y) if act == 2 else y)
+    if temb is not None:
+        y = y + temb[:, :, None, None]
+    return y
+
+
+def pack3(w):
+    out = torch.empty(w.numel(), device="cuda")
+    call("ddpm_pack_conv3x3", P(w.cuda().contiguous()), w.shape[0], w.shape[1], 0, P(out), stream())
+    return out
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, act, scale, residual, temb
+    (2, 8, 8, 8, 8, 0, False, False, False),
+    (3, 7, 7, 64, 128, 1, True, False, False),
+    (2, 28, 28, 64, 64, 2, True, True, True),
+    (1, 30, 30, 128, 256, 2, True, True, False),
+    (2, 14, 14, 256, 128, 1, False, False, True),
+    (2, 7, 7, 256, 512, 0, False, False, False),
+    (1, 9, 5, 16, 40, 2, True, False, True),
+    (5, 16, 16, 512, 512, 1, True, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3(case):
+    B, H, W, ci, co, act, use_scale, use_res, use_temb = case
+    x, w = rnd((B, ci, H, W), 1), rnd((co, ci, 3, 3), 2, (9 * ci) ** -0.5)
+    shift = rnd((co,), 3, 0.1)
+    scale = rnd((co,), 4).abs() + 0.5 if use_scale else None
+    res = rnd((B, co, H, W), 5) if use_res else None
+    temb = rnd((B, co), 6) if use_temb else None
+    xd = to_nhwc(x)
+    out = torch.full((B, H, W, co), float("nan"), device="cuda")
+    resd = to_nhwc(res) if use_res else None
+    d = ConvDesc(batch=B, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=act, ldr=co, out_h=H, out_w=W)
+    keep = [scale.cuda() if use_scale else None, shift.cuda(), temb.cuda() if use_temb else None]
+    ep = Epilogue(P(keep[0]), P(keep[1]), P(resd), P(keep[2]))
+    call("ddpm_conv3x3_fwd", C.byref(d), P(xd), None, P(pack3(w)), C.byref(ep), P(out), stream())
+    assert_close(from_nhwc(out), conv_ref(x, w, None, scale, shift, res, temb, act), TOL, f"conv3x3 {case}")
+
+
+def test_conv3x3_two_sources_and_strided_output():
+    """Input = channel concat of two tensors with their own pixel strides; output into a wider buffer."""
+    B, H, W, c1, c2, co = 2, 12, 10, 24, 40, 48
+    xa, xb, w = rnd((B, c1, H, W), 1), rnd((B, c2, H, W), 2), rnd((co, c1 + c2, 3, 3), 3, 0.05)
+    bufa = torch.zeros((B, H, W, c1 + 8), device="cuda")
+    bufa[..., :c1] = to_nhwc(xa)
+    bufb = torch.zeros((B, H, W, c2 + 4), device="cuda")
+    bufb[..., 4:] = to_nhwc(xb)
+    out = torch.full((B, H, W, co + 16), 7.0, device="cuda")
+    d = ConvDesc(batch=B, in_h=H, in_w=W, c1=c1, ld1=c1 + 8, c2=c2, ld2=c2 + 4, cout=co, ldo=co + 16, act=0, ldr=0, out_h=H, out_w=W)
+    ep = Epilogue(None, None, None, None)
+    call("ddpm_conv3x3_fwd", C.byref(d), P(bufa), C.c_void_p(bufb.data_ptr() + 16), P(pack3(w)), C.byref(ep),
+         C.c_void_p(out.data_ptr() + 32), stream())
+    want = F.conv2d(torch.cat([xa, xb], 1), w, padding=1)
+    assert_close(from_nhwc(out[..., 8:8 + co]), want, TOL, "dual-source conv")
+    assert torch.all(out[..., :8] == 7.0) and torch.all(out[..., 8 + co:] == 7.0)      # nothing outside the slice
+
+
+@pytest.mark.parametrize("case", [(2, 49, 64, 80), (3, 100, 8, 24), (1, 1024, 128, 160), (2, 64, 512, 640)])
+def test_conv1x1(case):
+    B, N, ci, co = case
+    x, w, b = rnd((B, ci, N, 1), 1), rnd((co, ci), 2, ci ** -0.5), rnd((co,), 3)
+    out = torch.empty((B, N, 1, co), device="cuda")
+    d = ConvDesc(batch=B, in_h=N, in_w=1, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=0, ldr=0, out_h=N, out_w=1)
+    bd, wd = b.cuda(), w.cuda()
+    ep = Epilogue(None, P(bd), None, None)
+    call("ddpm_conv1x1_fwd", C.byref(d), P(to_nhwc(x)), None, P(wd), C.byref(ep), P(out), stream())
+    assert_close(from_nhwc(out), F.conv2d(x, w[:, :, None, None], b), TOL, f"conv1x1 {case}")
+
+
+@pytest.mark.parametrize("case", [(2, 7, 7, 64, 32, 14, 14), (2, 7, 7, 32, 16, 15, 15), (2, 16, 16, 32, 16, 16, 16),
+                                  (1, 14, 14, 128, 64, 28, 28), (3, 15, 15, 8, 4, 15, 15), (2, 7, 5, 16, 8, 17, 9)])
+def test_convT2x2_pad_crop(case):
+    B, H, W, ci, co, OH, OW = case
+    x, w, b = rnd((B, ci, H, W), 1), rnd((ci, co, 2, 2), 2, ci ** -0.5), rnd((co,), 3)
+    y = F.conv_transpose2d(x, w, b, stride=2)
+    dy, dx = OH - y.shape[2], OW - y.shape[3]
+    want = F.pad(y, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+    wp = torch.empty(w.numel(), device="cuda")
+    call("ddpm_pack_convT2x2", P(w.cuda()), ci, co, P(wp), stream())
+    out = torch.zeros((B, OH, OW, co), device="cuda")
+    d = ConvDesc(batch=B, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=0, ldr=0, out_h=OH, out_w=OW,
+                 off_y=dy // 2, off_x=dx // 2)
+    bd = b.cuda()
+    ep = Epilogue(None, P(bd), None, None)
+    call("ddpm_convT2x2_fwd", C.byref(d), P(to_nhwc(x)), P(wp), C.byref(ep), P(out), stream())
+    assert_close(from_nhwc(out), want, TOL, f"convT {case}")
+
+
+@pytest.mark.parametrize("cin", [1, 3])
+def test_first_and_final_conv(cin):
+    B, H, W, co = 3, 11, 13, 16
+    x, w = rnd((B, cin, H, W), 1), rnd((co, cin, 3, 3), 2, 0.3)
+    scale, shift, temb = rnd((co,), 3).abs() + 0.5, rnd((co,), 4), rnd((B, co), 5)
+    out = torch.empty((B, H, W, co), device="cuda")
+    keep = [scale.cuda(), shift.cuda(), temb.cuda(), w.cuda()]
+    ep = Epilogue(P(keep[0]), P(keep[1]), None, P(keep[2]))
+    call("ddpm_conv3x3_first_fwd", P(x.cuda()), P(keep[3]), C.byref(ep), 2, P(out), B, cin, H, W, co, co, stream())
+    assert_close(from_nhwc(out), conv_ref(x, w, None, scale, shift, None, temb, 2), 1e-6, "first conv")
+    # final 1x1: NHWC (64 or 8 channels) -> NCHW
+    for c in (8, 64, 72):
+        xin, wf, bf = rnd((B, c, H, W), 6), rnd((cin, c), 7, c ** -0.5), rnd((cin,), 8)
+        o = torch.empty((B, cin, H, W), device="cuda")
+        call("ddpm_conv1x1_final_fwd", P(to_nhwc(xin)), c, P(wf.cuda()), P(bf.cuda()), P(o), B, H, W, c, cin, stream())
+        assert_close(o.cpu(), F.conv2d(xin, wf[:, :, None, None], bf), 1e-6, "final conv")
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 16), (3, 7, 7, 8), (2, 15, 9, 64), (1, 28, 28, 128)])
+def test_pool_skip_and_add_temb(case):
+    B, H, W, c = case
+    x, temb = rnd((B, c, H, W), 1), rnd((B, c), 2)
+    skip = torch.full((B, H, W, c + 4), 9.0, device="cuda")
+    pooled = torch.empty((B, H // 2, W // 2, c), device="cuda")
+    amax = torch.empty((B, H // 2, W // 2, c), dtype=torch.uint8, device="cuda")
+    xd, td = to_nhwc(x), temb.cuda()
+    call("ddpm_pool_skip_fwd", P(xd), c, P(td), P(skip), c + 4, P(pooled), c, P(amax), B, H, W, c, stream())
+    assert torch.equal(from_nhwc(skip[..., :c]), x + temb[:, :, None, None])
+    want, idx = F.max_pool2d(x, 2, 2, return_indices=True)
+    assert torch.equal(from_nhwc(pooled), want)
+    iy, ix = idx // W, idx % W
+    assert torch.equal(from_nhwc(amax).long(), (iy % 2) * 2 + (ix % 2))
+    out = torch.empty((B, H, W, c), device="cuda")
+    call("ddpm_add_temb", P(xd), c, P(td), P(out), c, B, H * W, c, stream())
+    assert torch.equal(from_nhwc(out), x + temb[:, :, None, None])
+
+
+# ---------------------------------------------------------------- attention
+@pytest.mark.parametrize("case", [(2, 49, 64, 8), (2, 196, 32, 4), (1, 1024, 128, 16), (2, 64, 512, 64), (2, 100, 8, 1),
+                                  (1, 784, 128, 16), (3, 33, 256, 32)])
+def test_attention_fwd(case):
+    B, N, c, dq = case
+    dqp = (dq + 7) // 8 * 8
+    x = rnd((B, N, c), 1)
+    q, k, v = rnd((B, N, dq), 2), rnd((B, N, dq), 3), rnd((B, N, c), 4)
+    gamma, temb = torch.tensor([0.37]), rnd((B, c), 5)
+    qkv = torch.zeros((B, N, 2 * dqp + c))
+    qkv[..., :dq], qkv[..., dqp:dqp + dq], qkv[..., 2 * dqp:] = q, k, v
+    a = torch.softmax(torch.bmm(q.double(), k.double().transpose(1, 2)), dim=-1)
+    raw_want = torch.bmm(a, v.double())
+    want = gamma.double() * raw_want + x.double() + temb.double()[:, None, :]
+    lse_want = torch.logsumexp(torch.bmm(q.double(), k.double().transpose(1, 2)), dim=-1)
+    out = torch.empty((B, N, c), device="cuda")
+    raw = torch.empty((B, N, c), device="cuda")
+    lse = torch.empty((B, N), device="cuda")
+    keep = [qkv.cuda(), x.cuda(), gamma.cuda(), temb.cuda()]
+    call("ddpm_attention_fwd", P(keep[0]), P(keep[1]), c, P(keep[2]), P(out), c, P(raw), P(lse), P(keep[3]), B, N, c, dqp, stream())
+    assert_close(out.cpu(), want, TOL, f"attention {case}")
+    assert_close(raw.cpu(), raw_want, TOL, f"attention raw {case}")
+    assert_close(lse.cpu(), lse_want, TOL, f"attention lse {case}")
+
+
+def test_attention_large_logits_rescale():
+    """One key dominates from a late tile on: forces the online-softmax rescale branch."""
+    B, N, c, dq = 1, 160, 32, 8
+    q, k, v, x = rnd((B, N, dq), 1), rnd((B, N, dq), 2), rnd((B, N, c), 3), rnd((B, N, c), 4)
+    k[0, 130] = q[0, 5] * 8.0          # key 130 (5th tile) spikes for query 5 (and correlates with others)
+    k[0, 3] = q[0, 70] * 6.0
+    qkv = torch.cat([q, k, v], -1)
+    a = torch.softmax(torch.bmm(q.double(), k.double().transpose(1, 2)), dim=-1)
+    want = 1.0 * torch.bmm(a, v.double()) + x.double()
+    out = torch.empty((B, N, c), device="cuda")
+    keep = [qkv.cuda(), x.cuda(), torch.ones(1, device="cuda")]
+    call("ddpm_attention_fwd", P(keep[0]), P(keep[1]), c, P(keep[2]), P(out), c, None, None, None, B, N, c, dq, stream())
+    assert_close(out.cpu(), want, TOL, "attention rescale")

@@ -1,0 +1,93 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every declared symbol, and its
+host-side tables are bit-identical to the reference's (tests/golden/schedules.npz)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+import diffusion_model_amd as pkg
+from diffusion_model_amd import _lib, schedule
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ddpm_mi355x.h")).read()
+    declared = set(re.findall(r"\b(ddpm_[A-Za-z0-9_]+)\s*\(", hdr))
+    declared -= {"ddpm_conv_desc", "ddpm_epilogue", "ddpm_embed_args"}
+    handle = C.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(handle, s)]
+    assert not missing, missing
+    assert set(_lib.exported_symbols()) == declared      # the ctypes table covers the whole header
+    assert _lib.lib().ddpm_abi_version() >= 1
+
+
+@pytest.mark.parametrize("kind", ["linear", "quadratic", "cosine"])
+@pytest.mark.parametrize("T", [10, 100, 1000])
+def test_tables_bit_exact(kind, T):
+    g = load_golden("schedules.npz")
+    betas = pkg.BetaScheduler(T).get_schedule(kind)
+    assert betas.dtype == torch.float32 and betas.shape == (T,)
+    assert betas.numpy().tobytes() == g[f"{kind}_{T}_betas"].tobytes()
+    dm = pkg.make_diffusion_class(1)(None, betas, T)
+    assert dm.alpha_scheduler.numpy().tobytes() == g[f"{kind}_{T}_alphas"].tobytes()
+    assert dm.alpha_bar_scheduler.numpy().tobytes() == g[f"{kind}_{T}_alpha_bar"].tobytes()
+    assert dm.num_timesteps == T and dm.beta_scheduler is betas and dm.model is None
+
+
+def test_named_schedule_methods_and_bad_name():
+    s = pkg.BetaScheduler(50)
+    assert torch.equal(s.linear(), s.get_schedule("linear"))
+    assert torch.equal(s.quadratic(), s.get_schedule("quadratic"))
+    assert torch.equal(s.cosine(), s.get_schedule("cosine"))
+    with pytest.raises(ValueError, match="Invalid scheduler type"):
+        s.get_schedule("sigmoid")
+
+
+def test_step_coefficients_match_ieee_and_reference_within_ulp():
+    from oracle import ddpm_oracle as O
+    g = load_golden("schedules.npz")
+    betas = schedule.betas_host("linear", 1000, 1e-4, 0.02)
+    alphas, abar = schedule.tables_host(betas)
+    got = np.array([schedule.step_coefficients_host(betas[t], alphas[t], abar[t]) for t in range(1000)], dtype=np.float32)
+    want = np.array([O.step_coefficients(betas, alphas, abar, t) for t in range(1000)], dtype=np.float32)
+    assert got.tobytes() == want.tobytes()               # IEEE-correct fp32 ops on both sides
+    for i, nm in enumerate(("c1", "c2", "c3")):
+        a = got[:, i].view(np.int32).astype(np.int64)
+        b = g[f"linear_1000_{nm}_torchcpu"].view(np.int32).astype(np.int64)
+        assert np.abs(a - b).max() <= 2                   # torch's vectorised sqrt is 1 ulp off sometimes
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_state_dict_contract(variant):
+    import json
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "meta.json")))
+    U = pkg.make_unet_class(variant)
+    m = U(1, 1, 8, 16) if variant < 3 else U(3, 3, 8, 16, num_classes=10)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == meta[f"tiny_v{variant}"]["keys"]
+    assert m.feature_maps == []
+
+
+def test_no_cpu_fallback():
+    U = pkg.make_unet_class(1)
+    m = U(1, 1, 8, 16).eval()
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(torch.zeros(1, 1, 8, 8), torch.zeros(1, dtype=torch.long))
+    dm = pkg.make_diffusion_class(1)(m, pkg.BetaScheduler(10).get_schedule("linear"), 10)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        dm.add_noise(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8), torch.zeros(1, dtype=torch.long))
+
+
+def test_drop_in_modules_import_by_bare_name():
+    import subprocess
+    import sys
+    for d in ("first-iteration", "second-iteration", "third-iteration"):
+        code = ("import unet, diffusion, beta_scheduler, embeddings;"
+                "print(unet.UNet.__name__, diffusion.DiffusionModel.__name__, beta_scheduler.BetaScheduler.__name__,"
+                "embeddings.SinusoidalTimeEmbedding.__name__)")
+        r = subprocess.run([sys.executable, "-c", code], cwd=os.path.join(ROOT, "diffusion-model_amd", "drop_in", d),
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.split() == ["UNet", "DiffusionModel", "BetaScheduler", "SinusoidalTimeEmbedding"]
