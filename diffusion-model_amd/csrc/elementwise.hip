@@ -2,6 +2,9 @@
 // eps-MSE loss, max-pool + skip hand-off, time-embedding broadcast add.
 #include "common.h"
 
+// The process kernels promise separately rounded fp32 operations: never contract a*b+c into an FMA.
+#pragma clang fp contract(off)
+
 using ddpm::as_stream;
 
 namespace {
@@ -79,9 +82,11 @@ __global__ __launch_bounds__(kThreads) void add_noise_kernel(const float* __rest
     const int chunk = blockIdx.x % blocks_per_sample;
     int64_t ti = t[b];
     if (ti < 0) ti += timesteps;               // python-style negative index
+    ti = ti < 0 ? 0 : (ti >= timesteps ? timesteps - 1 : ti);   // memory safety; the host validates the range
     const float ab = abar[ti];
-    const float s1 = __fsqrt_rn(ab);
-    const float s2 = __fsqrt_rn(__fsub_rn(1.0f, ab));
+    // sqrtf is the correctly rounded square root here (hipcc's default); __fsqrt_rn is the 1-ulp native one
+    const float s1 = sqrtf(ab);
+    const float s2 = sqrtf(__fsub_rn(1.0f, ab));
     const float* xs = x0 + static_cast<int64_t>(b) * per_sample;
     const float* ns = noise + static_cast<int64_t>(b) * per_sample;
     float* os = out + static_cast<int64_t>(b) * per_sample;

@@ -32,3 +32,13 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_temporaries():
+    yield
+    try:
+        from gpu_util import release_kept
+    except Exception:
+        return
+    release_kept()

@@ -6,8 +6,22 @@ import torch
 from diffusion_model_amd._lib import ConvDesc, Epilogue, call  # noqa: F401
 
 
+_keepalive = []
+
+
 def P(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    """Device pointer of `t`. The tensor is kept alive until the end of the test (release_kept),
+    so temporaries like P(x.cuda()) cannot be recycled by the allocator before the kernel runs."""
+    if t is None:
+        return None
+    _keepalive.append(t)
+    return C.c_void_p(t.data_ptr())
+
+
+def release_kept():
+    if _keepalive and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    _keepalive.clear()
 
 
 def stream():
