@@ -70,6 +70,24 @@ class UNetEngine:
         self.num_classes = num_classes
         self._cache = {}
         self._tensors = None
+        self.prof = None       # when a list: (kernel label, flops, start event, end event) per MFMA launch
+
+    def _gemm_label(self, kind, m, n):
+        """Name of the conv_gemm_kernel instance the library picks for an m x n problem."""
+        pad128, pad64 = _round_up(n, 128), _round_up(n, 64)
+        bm, bn = 128, (128 if pad128 <= pad64 else 64)
+        if _round_up(m, bm) // bm * (_round_up(n, bn) // bn) < 256:
+            bm = bn = 64
+        return f"conv_gemm<{bm}x{bn},{kind}>"
+
+    def _launch(self, label, flops, name, *args):
+        if self.prof is None:
+            return call(name, *args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call(name, *args)
+        e1.record()
+        self.prof.append((label, flops, e0, e1))
 
     # ------------------------------------------------------------------ entry point
     def invalidate(self):
@@ -154,14 +172,18 @@ class UNetEngine:
         d = ConvDesc(batch=b, in_h=h, in_w=w, c1=src.c, ld1=src.ld, c2=0, ld2=0, cout=cout, ldo=out.ld, act=act,
                      ldr=residual.ld if residual is not None else 0, out_h=h, out_w=w, off_y=0, off_x=0)
         ep = Epilogue(_ptr(scale), _ptr(shift), residual.ptr if residual is not None else None, _ptr(temb))
-        call("ddpm_conv3x3_fwd", C.byref(d), src.ptr, None, _ptr(wkey_packed), C.byref(ep), out.ptr, _stream())
+        m = b * h * w
+        self._launch(self._gemm_label("conv3x3", m, cout), 2.0 * m * cout * 9 * src.c, "ddpm_conv3x3_fwd", C.byref(d), src.ptr,
+                     None, _ptr(wkey_packed), C.byref(ep), out.ptr, _stream())
 
     def conv1x1(self, src, w, bias, cout, out):
         b, h, wd = src.bhw
         d = ConvDesc(batch=b, in_h=h, in_w=wd, c1=src.c, ld1=src.ld, c2=0, ld2=0, cout=cout, ldo=out.ld, act=ACT_NONE,
                      ldr=0, out_h=h, out_w=wd, off_y=0, off_x=0)
         ep = Epilogue(None, _ptr(bias), None, None)
-        call("ddpm_conv1x1_fwd", C.byref(d), src.ptr, None, _ptr(w), C.byref(ep), out.ptr, _stream())
+        m = b * h * wd
+        self._launch(self._gemm_label("conv1x1", m, cout), 2.0 * m * cout * src.c, "ddpm_conv1x1_fwd", C.byref(d), src.ptr, None,
+                     _ptr(w), C.byref(ep), out.ptr, _stream())
 
     def convT(self, src, key, out):
         """ConvTranspose2d(k=2,s=2) of `src`, padded/cropped (centre, floor-division offsets) into `out`."""
@@ -270,8 +292,9 @@ class UNetEngine:
             raw = torch.empty((b, h, w, c), device=x.buf.device, dtype=torch.float32)
             lse = torch.empty((b, h * w), device=x.buf.device, dtype=torch.float32)
             save.update(qkv=qkv, raw=raw, lse=lse)
-        call("ddpm_attention_fwd", qkv.ptr, x.ptr, x.ld, _ptr(self.T(key + ".gamma")), out.ptr, out.ld, _ptr(raw), _ptr(lse),
-             _ptr(temb), b, h * w, c, dqp, _stream())
+        n = h * w
+        self._launch("attention_fwd", 2.0 * b * n * n * (dqp + c), "ddpm_attention_fwd", qkv.ptr, x.ptr, x.ld,
+                     _ptr(self.T(key + ".gamma")), out.ptr, out.ld, _ptr(raw), _ptr(lse), _ptr(temb), b, n, c, dqp, _stream())
 
     # ------------------------------------------------------------------ whole network, eval mode
     def forward_eval(self, x, t, y=None, want_fms=True):
