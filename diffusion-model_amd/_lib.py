@@ -21,6 +21,13 @@ class Epilogue(C.Structure):
     _fields_ = [("scale", P), ("shift", P), ("residual", P), ("temb", P)]
 
 
+class EmbedBwdArgs(C.Structure):
+    _fields_ = [("batch", I32), ("emb_dim", I32), ("n_labels", I32), ("reserved", I32),
+                ("emb", P), ("y", P), ("label_table", P),
+                ("ch", I32 * 4), ("dtemb", P * 4), ("lw", P * 4), ("dw", P * 4), ("db", P * 4), ("dlw", P * 4), ("dlb", P * 4),
+                ("dlabel_table", P)]
+
+
 class EmbedArgs(C.Structure):
     _fields_ = [("batch", I32), ("emb_dim", I32), ("n_labels", I32), ("t_is_float", I32),
                 ("t", P), ("y", P), ("label_table", P),
@@ -49,6 +56,21 @@ _SIGNATURES = {
     "ddpm_conv1x1_final_fwd": [P, I32, P, P, P, I32, I32, I32, I32, I32, P],
     "ddpm_pool_skip_fwd": [P, I32, P, P, I32, P, I32, P, I32, I32, I32, I32, P],
     "ddpm_add_temb": [P, I32, P, P, I32, I32, I32, I32, P],
+    "ddpm_bn_stats": [P, I32, I64, I32, F32, F32, P, P, P, P, P, P],
+    "ddpm_bn_apply_fwd": [P, I32, P, P, P, P, P, I32, P, I32, P, I32, I32, I32, I32, P],
+    "ddpm_bn_bwd": [P, I32, P, I32, P, I32, P, P, P, P, I32, I64, I32, P, P, P, P, I32, P, I32, P, I32, P, P],
+    "ddpm_colsum": [P, I32, I32, I64, I32, P, I32, P, P],
+    "ddpm_conv3x3_wgrad": [P, I32, I32, P, I32, I32, I32, I32, I32, P, P, P],
+    "ddpm_conv1x1_wgrad": [P, I32, I32, P, I32, I32, I64, P, P],
+    "ddpm_pack_convT2x2_dgrad": [P, I32, I32, P, P],
+    "ddpm_convT2x2_dgrad": [C.POINTER(ConvDesc), P, P, C.POINTER(Epilogue), P, P],
+    "ddpm_convT2x2_wgrad": [P, I32, I32, I32, I32, I32, I32, P, I32, I32, I32, I32, I32, P, P, P],
+    "ddpm_conv3x3_first_wgrad": [P, I32, P, P, P, I32, I32, I32, I32, I32, P],
+    "ddpm_conv1x1_final_bwd": [P, P, I32, P, P, P, I32, P, P, I32, I32, I32, I32, I32, P],
+    "ddpm_pool_skip_bwd": [P, I32, P, I32, P, P, I32, I32, I32, I32, I32, P],
+    "ddpm_colsum_window": [P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P, P, P],
+    "ddpm_time_embed_bwd": [C.POINTER(EmbedBwdArgs), P],
+    "ddpm_attention_bwd": [P, P, I32, P, P, P, P, P, P, P, I32, I32, I32, I32, P],
     "ddpm_attention_fwd": [P, P, I32, P, P, I32, P, P, P, I32, I32, I32, I32, P],
 }
 
@@ -68,6 +90,8 @@ def lib():
         handle = C.CDLL(LIB_PATH)
         handle.ddpm_last_error.restype = C.c_char_p
         handle.ddpm_last_error.argtypes = []
+        handle.ddpm_reduce_workspace_doubles.restype = C.c_int64
+        handle.ddpm_reduce_workspace_doubles.argtypes = [I32]
         for name, sig in _SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the header and library disagree
             fn.argtypes = sig
@@ -77,7 +101,7 @@ def lib():
 
 
 def exported_symbols():
-    return ["ddpm_last_error"] + list(_SIGNATURES)
+    return ["ddpm_last_error", "ddpm_reduce_workspace_doubles"] + list(_SIGNATURES)
 
 
 def call(name, *args):

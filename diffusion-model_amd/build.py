@@ -13,7 +13,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libddpm_mi355x.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function", "-fno-gpu-rdc"]
+         "-Wno-unused-function", "-fno-gpu-rdc", "-munsafe-fp-atomics"]
 
 
 def _sources():

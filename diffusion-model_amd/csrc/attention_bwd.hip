@@ -1,0 +1,410 @@
+// Backward of the flash-style self-attention (see attention.hip), recomputing the probabilities
+// from the saved row log-sum-exp. With  y = gamma*O + x,  O = P V,  P = softmax(Q K^T):
+//
+//   E_i   = sum_c dY[i][c] * O[i][c]            dgamma = sum_i E_i,   D_i = gamma * E_i
+//   dO    = gamma * dY
+//   dV[j] = sum_i P_ij dO[i]                    dP_ij = dO[i] . V[j]
+//   dS_ij = P_ij (dP_ij - D_i)
+//   dQ[i] = sum_j dS_ij K[j]                    dK[j] = sum_i dS_ij Q[i]
+//
+// Two MFMA kernels avoid atomics: `dkv` gives every wave 32 keys and walks the queries (tiles in
+// "lane = key, register = query" orientation, so the query-axis contractions for dV and dK take the
+// score registers directly as MFMA B operands); `dq` gives every wave 32 queries and walks the keys
+// in the transposed orientation. The x-gradient pass-through (dx += dY) is the caller's.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TQ = 32;
+
+__device__ __forceinline__ int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+struct BwdParams {
+    const float* qkv;    // [B][N][lq]
+    const float* dy;     // [B][N][.] stride ldd
+    const float* o;      // [B][N][C] attention output before the gate
+    const float* lse;    // [B][N]
+    const float* e;      // [B][N]  rowwise dY.O
+    const float* gamma;
+    float* dqkv;         // [B][N][lq]
+    int n, c, dqp, lq, ldd;
+};
+
+// E[b][i] = dY[i].O[i]; partial sums of E per workgroup for dgamma
+__global__ __launch_bounds__(256) void attn_bwd_pre_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ o, int c,
+                                                            int64_t rows, float* __restrict__ e, double* __restrict__ partial) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + wave; r < rows; r += static_cast<int64_t>(gridDim.x) * 4) {
+        float s = 0.f;
+        for (int ch = lane * 4; ch < c; ch += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(dy + r * ldd + ch);
+            const float4 b = *reinterpret_cast<const float4*>(o + r * c + ch);
+            s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) {
+            e[r] = s;
+            acc += s;
+        }
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void attn_bwd_dgamma_kernel(const double* __restrict__ partial, int n, float* __restrict__ dgamma) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dgamma[0] = static_cast<float>(red[0]);
+}
+
+// ---- dK, dV: wave = 32 keys, loop over query tiles -------------------------------------------
+// grid (ceil(N/128), ceil(C/CS), B). Every channel-slice block recomputes S and the full dP; only
+// slice 0 accumulates dK.
+template <int DQ, int NCT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdParams p) {
+    constexpr int CS = 32 * NCT;
+    constexpr int QLD = DQ + 4;
+    constexpr int DT = (DQ + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int DLD = p.c + 4;
+    float* sQ = smem;                  // [TQ][QLD]
+    float* sDO = sQ + TQ * QLD;        // [TQ][DLD]   gamma * dY
+    float* sL = sDO + TQ * DLD;        // [TQ] lse
+    float* sD = sL + TQ;               // [TQ] D_i
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int cbase = blockIdx.y * CS;
+    const int j0 = (blockIdx.x * 4 + wave) * 32;
+    const bool wave_active = j0 < p.n;
+    const int kj = j0 + r;  // this lane's key
+    const float g = p.gamma[0];
+    const float* base = p.qkv + static_cast<int64_t>(b) * p.n * p.lq;
+    const float* dyb = p.dy + static_cast<int64_t>(b) * p.n * p.ldd;
+
+    // K fragment (B operand of S = Q K^T): element e of chunk kk is K[kj][8kk + 4h + e]
+    f32x4 kf[DQ / 8];
+#pragma unroll
+    for (int kk = 0; kk < DQ / 8; ++kk) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kj < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(kj) * p.lq + p.dqp + kk * 8 + h * 4);
+        kf[kk] = v;
+    }
+    const float* vrow = base + static_cast<int64_t>(kj < p.n ? kj : 0) * p.lq + 2 * p.dqp;
+
+    f32x16 dv[NCT], dk[DT];
+#pragma unroll
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dv[t][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dk[t][e] = 0.f;
+
+    const int qtiles = (p.n + TQ - 1) / TQ;
+    const int c4n = p.c >> 2;
+    for (int t = 0; t < qtiles; ++t) {
+        const int i0 = t * TQ;
+        __syncthreads();
+        for (int f = tid; f < TQ * (DQ / 4); f += 256) {
+            const int row = f / (DQ / 4), c4 = f % (DQ / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i0 + row < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(i0 + row) * p.lq + c4 * 4);
+            *reinterpret_cast<f32x4*>(sQ + row * QLD + c4 * 4) = v;
+        }
+        for (int f = tid; f < TQ * c4n; f += 256) {
+            const int row = f / c4n, c4 = f % c4n;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i0 + row < p.n) v = *reinterpret_cast<const f32x4*>(dyb + static_cast<int64_t>(i0 + row) * p.ldd + c4 * 4);
+            *reinterpret_cast<f32x4*>(sDO + row * DLD + c4 * 4) = v * g;
+        }
+        if (tid < TQ) {
+            const bool ok = i0 + tid < p.n;
+            sL[tid] = ok ? p.lse[static_cast<int64_t>(b) * p.n + i0 + tid] : 0.f;
+            sD[tid] = ok ? g * p.e[static_cast<int64_t>(b) * p.n + i0 + tid] : 0.f;
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+
+        // S[i][j]: lane = key j, register = query i = rowmap(reg, h)
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < DQ / 8; ++kk) {
+            const f32x4 qf = *reinterpret_cast<const f32x4*>(sQ + r * QLD + kk * 8 + h * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[e], kf[kk][e], s, 0, 0, 0);
+        }
+        // dP[i][j] = dO[i] . V[j]   (contraction over all C channels)
+        f32x16 dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+        for (int kk = 0; kk < p.c / 8; ++kk) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sDO + r * DLD + kk * 8 + h * 4);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(vrow + kk * 8 + h * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], vv[e], dp, 0, 0, 0);
+        }
+        if ((p.c & 7) != 0) {  // C = 4 (mod 8): last half chunk, only the h = 0 lanes carry data
+            const int kk = p.c / 8;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (h == 0) {
+                a = *reinterpret_cast<const f32x4*>(sDO + r * DLD + kk * 8);
+                vv = *reinterpret_cast<const f32x4*>(vrow + kk * 8);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], vv[e], dp, 0, 0, 0);
+        }
+        // P and dS (in place: s -> P, dp -> dS)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int il = rowmap(e, h);
+            const bool ok = (i0 + il < p.n) && (kj < p.n);
+            const float pe = ok ? expf(s[e] - sL[il]) : 0.f;
+            s[e] = pe;
+            dp[e] = pe * (dp[e] - sD[il]);
+        }
+        // dV^T[c][j] += sum_i dO[i][c] P[i][j]
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int ch = cbase + ct * 32 + r;
+            const bool ch_ok = ch < p.c;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float a = ch_ok ? sDO[rowmap(e, h) * DLD + ch] : 0.f;
+                dv[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[e], dv[ct], 0, 0, 0);
+            }
+        }
+        // dK^T[d][j] += sum_i Q[i][d] dS[i][j]
+        if (blockIdx.y == 0) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 32 + r;
+                const bool d_ok = d < DQ;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float a = d_ok ? sQ[rowmap(e, h) * QLD + d] : 0.f;
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dp[e], dk[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    if (!wave_active || kj >= p.n) return;
+    float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + kj) * p.lq;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int ch = cbase + ct * 32 + gq * 8 + h * 4;
+            if (ch >= p.c) continue;
+            f32x4 v = {dv[ct][gq * 4], dv[ct][gq * 4 + 1], dv[ct][gq * 4 + 2], dv[ct][gq * 4 + 3]};
+            *reinterpret_cast<f32x4*>(drow + 2 * p.dqp + ch) = v;
+        }
+    if (blockIdx.y == 0) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d = dt * 32 + gq * 8 + h * 4;
+                if (d >= DQ) continue;
+                f32x4 v = {dk[dt][gq * 4], dk[dt][gq * 4 + 1], dk[dt][gq * 4 + 2], dk[dt][gq * 4 + 3]};
+                *reinterpret_cast<f32x4*>(drow + p.dqp + d) = v;
+            }
+    }
+}
+
+// ---- dQ: wave = 32 queries, loop over key tiles ------------------------------------------------
+template <int DQ>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdParams p) {
+    constexpr int KLD = DQ + 4;
+    constexpr int DT = (DQ + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int VLD = p.c + 4;
+    float* sK = smem;             // [32][KLD]
+    float* sV = sK + 32 * KLD;    // [32][VLD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int i0 = (blockIdx.x * 4 + wave) * 32;
+    const bool wave_active = i0 < p.n;
+    const int qi = i0 + r;
+    const bool q_ok = qi < p.n;
+    const float g = p.gamma[0];
+    const float* base = p.qkv + static_cast<int64_t>(b) * p.n * p.lq;
+    const float* dyrow = p.dy + (static_cast<int64_t>(b) * p.n + (q_ok ? qi : 0)) * p.ldd;
+
+    f32x4 qf[DQ / 8];
+#pragma unroll
+    for (int kk = 0; kk < DQ / 8; ++kk) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q_ok) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(qi) * p.lq + kk * 8 + h * 4);
+        qf[kk] = v;
+    }
+    const float lse_i = q_ok ? p.lse[static_cast<int64_t>(b) * p.n + qi] : 0.f;
+    const float d_i = q_ok ? g * p.e[static_cast<int64_t>(b) * p.n + qi] : 0.f;
+
+    f32x16 dq[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[t][e] = 0.f;
+
+    const int ktiles = (p.n + 31) / 32;
+    const int c4n = p.c >> 2;
+    for (int t = 0; t < ktiles; ++t) {
+        const int j0 = t * 32;
+        __syncthreads();
+        for (int f = tid; f < 32 * (DQ / 4); f += 256) {
+            const int row = f / (DQ / 4), c4 = f % (DQ / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + row < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(j0 + row) * p.lq + p.dqp + c4 * 4);
+            *reinterpret_cast<f32x4*>(sK + row * KLD + c4 * 4) = v;
+        }
+        for (int f = tid; f < 32 * c4n; f += 256) {
+            const int row = f / c4n, c4 = f % c4n;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + row < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(j0 + row) * p.lq + 2 * p.dqp + c4 * 4);
+            *reinterpret_cast<f32x4*>(sV + row * VLD + c4 * 4) = v;
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+
+        // S^T[j][i]: lane = query, register = key rowmap(reg, h)
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < DQ / 8; ++kk) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(sK + r * KLD + kk * 8 + h * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[kk][e], s, 0, 0, 0);
+        }
+        // dP^T[j][i] = V[j] . dO[i]
+        f32x16 dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+        for (int kk = 0; kk < p.c / 8; ++kk) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sV + r * VLD + kk * 8 + h * 4);
+            f32x4 dd = *reinterpret_cast<const f32x4*>(dyrow + kk * 8 + h * 4);
+            dd = dd * g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], dd[e], dp, 0, 0, 0);
+        }
+        if ((p.c & 7) != 0) {
+            const int kk = p.c / 8;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, dd = {0.f, 0.f, 0.f, 0.f};
+            if (h == 0) {
+                a = *reinterpret_cast<const f32x4*>(sV + r * VLD + kk * 8);
+                dd = *reinterpret_cast<const f32x4*>(dyrow + kk * 8);
+                dd = dd * g;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], dd[e], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool ok = q_ok && (j0 + rowmap(e, h) < p.n);
+            const float pe = ok ? expf(s[e] - lse_i) : 0.f;
+            dp[e] = pe * (dp[e] - d_i);
+        }
+        // dQ^T[d][i] += sum_j K[j][d] dS[i][j]
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 32 + r;
+            const bool d_ok = d < DQ;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float a = d_ok ? sK[rowmap(e, h) * KLD + d] : 0.f;
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dp[e], dq[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (!wave_active || !q_ok) return;
+    float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + qi) * p.lq;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int d = dt * 32 + gq * 8 + h * 4;
+            if (d >= DQ) continue;
+            f32x4 v = {dq[dt][gq * 4], dq[dt][gq * 4 + 1], dq[dt][gq * 4 + 2], dq[dt][gq * 4 + 3]};
+            *reinterpret_cast<f32x4*>(drow + d) = v;
+        }
+}
+
+template <int DQ>
+int launch_bwd(const BwdParams& p, int batch, hipStream_t s) {
+    const int blocks_n = (p.n + 127) / 128;
+    const size_t lds_kv = sizeof(float) * (TQ * (DQ + 4) + TQ * (p.c + 4) + 2 * TQ);
+    const size_t lds_q = sizeof(float) * (32 * (DQ + 4) + 32 * (p.c + 4));
+    if (p.c > 64) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DQ, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds_kv)) != hipSuccess)
+            return ddpm::fail_invalid("LDS size for attention backward (dkv)");
+        attn_bwd_dkv_kernel<DQ, 4><<<dim3(blocks_n, (p.c + 127) / 128, batch), 256, lds_kv, s>>>(p);
+    } else if (p.c > 32) {
+        attn_bwd_dkv_kernel<DQ, 2><<<dim3(blocks_n, 1, batch), 256, lds_kv, s>>>(p);
+    } else {
+        attn_bwd_dkv_kernel<DQ, 1><<<dim3(blocks_n, 1, batch), 256, lds_kv, s>>>(p);
+    }
+    if (int rc = ddpm::check_launch("attn_bwd_dkv_kernel")) return rc;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<DQ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds_q)) != hipSuccess)
+        return ddpm::fail_invalid("LDS size for attention backward (dq)");
+    attn_bwd_dq_kernel<DQ><<<dim3(blocks_n, 1, batch), 256, lds_q, s>>>(p);
+    return ddpm::check_launch("attn_bwd_dq_kernel");
+}
+
+}  // namespace
+
+extern "C" int ddpm_attention_bwd(const float* qkv, const float* dy, int ldd, const float* attn_raw, const float* lse, const float* gamma,
+                                  double* workspace, float* e_scratch, float* dqkv, float* dgamma, int batch, int n, int c, int dq,
+                                  void* stream) {
+    DDPM_REQUIRE(qkv && dy && attn_raw && lse && gamma && workspace && e_scratch && dqkv && dgamma);
+    DDPM_REQUIRE(batch > 0 && batch <= 65535 && n > 0 && c > 0 && (c & 3) == 0 && c <= 1024 && (ldd & 3) == 0 && ldd >= c);
+    DDPM_REQUIRE(dq == 8 || dq == 16 || dq == 32 || dq == 64);
+    DDPM_REQUIRE(ddpm::aligned16(qkv) && ddpm::aligned16(dy) && ddpm::aligned16(attn_raw) && ddpm::aligned16(dqkv));
+    hipStream_t s = ddpm::as_stream(stream);
+    const int64_t rows = static_cast<int64_t>(batch) * n;
+    int pre_blocks = static_cast<int>((rows + 3) / 4 > 1024 ? 1024 : (rows + 3) / 4);
+    attn_bwd_pre_kernel<<<pre_blocks, 256, 0, s>>>(dy, ldd, attn_raw, c, rows, e_scratch, workspace);
+    attn_bwd_dgamma_kernel<<<1, 256, 0, s>>>(workspace, pre_blocks, dgamma);
+    if (int rc = ddpm::check_launch("attn_bwd_pre")) return rc;
+    BwdParams p;
+    p.qkv = qkv;
+    p.dy = dy;
+    p.o = attn_raw;
+    p.lse = lse;
+    p.e = e_scratch;
+    p.gamma = gamma;
+    p.dqkv = dqkv;
+    p.n = n;
+    p.c = c;
+    p.dqp = dq;
+    p.lq = 2 * dq + c;
+    p.ldd = ldd;
+    switch (dq) {
+        case 8: return launch_bwd<8>(p, batch, s);
+        case 16: return launch_bwd<16>(p, batch, s);
+        case 32: return launch_bwd<32>(p, batch, s);
+        default: return launch_bwd<64>(p, batch, s);
+    }
+}

@@ -27,6 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MODE_CONV3 = 0;  // 3x3, pad 1
 constexpr int MODE_CONV1 = 1;  // 1x1
 constexpr int MODE_CONVT = 2;  // 2x2 stride-2 transposed: GEMM + scatter
+constexpr int MODE_CONVT_DGRAD = 3;  // data gradient of MODE_CONVT: 4 taps gathered from the (out_h x out_w) image
 
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;  // padded row length in floats
@@ -129,12 +130,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
         const int cc = first ? c : c - p.c1;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int yy = ri[i].z + dy, xx = ri[i].w + dx;
-            const bool ok = c_ok && ri[i].x >= 0 && yy >= 0 && yy < p.in_h && xx >= 0 && xx < p.in_w;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const int64_t pix = static_cast<int64_t>(ri[i].x) + dy * p.in_w + dx;
-                v = *reinterpret_cast<const f32x4*>(base + pix * ld + cc);
+            if (MODE == MODE_CONVT_DGRAD) {
+                // tap = a*2 + b: the output pixel (2y+a+off_y, 2x+b+off_x) this input pixel fed
+                const int oy = 2 * ri[i].z + (tap >> 1) + p.off_y, ox = 2 * ri[i].w + (tap & 1) + p.off_x;
+                if (c_ok && ri[i].x >= 0 && oy >= 0 && oy < p.out_h && ox >= 0 && ox < p.out_w) {
+                    const int64_t pix = (static_cast<int64_t>(ri[i].y) * p.out_h + oy) * p.out_w + ox;
+                    v = *reinterpret_cast<const f32x4*>(base + pix * ld + cc);
+                }
+            } else {
+                const int yy = ri[i].z + dy, xx = ri[i].w + dx;
+                const bool ok = c_ok && ri[i].x >= 0 && yy >= 0 && yy < p.in_h && xx >= 0 && xx < p.in_w;
+                if (ok) {
+                    const int64_t pix = static_cast<int64_t>(ri[i].x) + dy * p.in_w + dx;
+                    v = *reinterpret_cast<const f32x4*>(base + pix * ld + cc);
+                }
             }
             areg[i] = v;
         }
@@ -335,6 +345,18 @@ __global__ void pack_convT_kernel(const float* __restrict__ w, int cin, int cout
     }
 }
 
+__global__ void pack_convT_dgrad_kernel(const float* __restrict__ w, int cin, int cout, float* __restrict__ out) {
+    const int64_t total = static_cast<int64_t>(cin) * cout * 4;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        // out[q][ci][co] = w[ci][co][q]
+        const int co = static_cast<int>(i % cout);
+        const int ci = static_cast<int>((i / cout) % cin);
+        const int q = static_cast<int>(i / (static_cast<int64_t>(cin) * cout));
+        out[i] = w[(static_cast<int64_t>(ci) * cout + co) * 4 + q];
+    }
+}
+
 }  // namespace
 
 extern "C" int ddpm_conv3x3_fwd(const ddpm_conv_desc* d, const float* src1, const float* src2, const float* w_packed,
@@ -404,4 +426,30 @@ extern "C" int ddpm_pack_convT2x2(const float* w, int cin, int cout, float* out,
     const int grid = static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     pack_convT_kernel<<<grid, 256, 0, as_stream(stream)>>>(w, cin, cout, out);
     return ddpm::check_launch("pack_convT_kernel");
+}
+
+extern "C" int ddpm_pack_convT2x2_dgrad(const float* w, int cin, int cout, float* out, void* stream) {
+    DDPM_REQUIRE(w && out && cout > 0 && cin > 0);
+    const int64_t total = static_cast<int64_t>(cout) * cin * 4;
+    const int grid = static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    pack_convT_dgrad_kernel<<<grid, 256, 0, as_stream(stream)>>>(w, cin, cout, out);
+    return ddpm::check_launch("pack_convT_dgrad_kernel");
+}
+
+// d->in_h/in_w: geometry of the transposed conv's INPUT (= of the gradient produced, `out`);
+// d->out_h/out_w/off_*: geometry/placement of its output (= of `dy`, c1 = its channels, ld1 its stride);
+// d->cout: channels of the gradient produced.
+extern "C" int ddpm_convT2x2_dgrad(const ddpm_conv_desc* d, const float* dy, const float* w_packed, const ddpm_epilogue* ep,
+                                   float* out, void* stream) {
+    if (int rc = validate_common(d, dy, nullptr, w_packed, ep, out)) return rc;
+    DDPM_REQUIRE(d->c2 == 0 && d->out_h > 0 && d->out_w > 0 && !ep->temb);
+    DDPM_REQUIRE(static_cast<int64_t>(d->batch) * d->out_h * d->out_w < (1ll << 31));
+    GemmParams p;
+    fill_common(p, d, dy, nullptr, w_packed, ep, out);
+    p.taps = 4;
+    p.out_h = d->out_h;
+    p.out_w = d->out_w;
+    p.off_y = d->off_y;
+    p.off_x = d->off_x;
+    return launch_gemm<MODE_CONVT_DGRAD>(p, as_stream(stream));
 }

@@ -1,0 +1,266 @@
+// Weight gradients of the convolutions as split-K GEMMs on the fp32 matrix cores:
+//
+//   dW[tap][m][n] = sum over pixels p of  A[pA(p,tap)][m] * B[pB(p,tap)][n]
+//
+//   3x3 conv : A = dY (m = output channel) at p,            B = X (n = input channel) at p + tap offset
+//   1x1 conv : A = dY at p,                                  B = X at p
+//   convT 2x2: A = dY at (2y+a+off_y, 2x+b+off_x), tap=(a,b), B = X at p           (m = cout, n = cin)
+//
+// The reduction axis (pixels) is the slow axis of both NHWC operands, so tiles are staged in LDS
+// K-major ([pixel][channel], a plain copy of 32 pixel rows) and the MFMA fragments are read with
+// conflict-free 4-byte reads (lane = channel). Pixels are split over workgroups; every workgroup
+// adds its partial tile into the packed result [tap][M][N] with fp32 atomics (contiguous along n),
+// which the caller has zeroed. A second tiny kernel permutes the packed result into torch's
+// parameter layout.
+#include "common.h"
+
+using ddpm::as_stream;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WG_CONV3 = 0;
+constexpr int WG_CONV1 = 1;
+constexpr int WG_CONVT = 2;
+constexpr int BKP = 32;  // pixels per K-step
+
+struct WgradParams {
+    const float* a;  // dY
+    const float* b;  // X
+    float* out;      // packed [taps][m_total][n_total]
+    int batch, h, w;          // image the reduction enumerates (= X's geometry)
+    int a_h, a_w;             // dY's geometry (differs for convT)
+    int m_total, lda, n_total, ldb;
+    int off_y, off_x, taps;
+    int k_total, k_chunk, splits;
+    int m_tiles, n_tiles;
+};
+
+template <int BT, int MODE>  // BT x BT output tile (channels x channels)
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+    constexpr int TT = BT / 64;           // 32x32 MFMA tiles per wave per dimension
+    constexpr int F4R = BT / 4;           // float4 per tile row
+    constexpr int LPT = BKP * F4R / 256;  // float4 loads per thread per operand
+    __shared__ __attribute__((aligned(16))) float sA[2][BKP * BT];
+    __shared__ __attribute__((aligned(16))) float sB[2][BKP * BT];
+
+    int id = blockIdx.x;
+    const int nt = id % p.n_tiles; id /= p.n_tiles;
+    const int mt = id % p.m_tiles; id /= p.m_tiles;
+    const int tap = id % p.taps;
+    const int split = id / p.taps;
+    const int m0 = mt * BT, n0 = nt * BT;
+    const int k_begin = split * p.k_chunk;
+    const int k_end = min(p.k_total, k_begin + p.k_chunk);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    int dy = 0, dx = 0;
+    if (MODE == WG_CONV3) {
+        dy = tap / 3 - 1;
+        dx = tap % 3 - 1;
+    }
+    const int per = p.h * p.w;
+
+    f32x16 acc[TT][TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 areg[LPT], breg[LPT];
+    auto load_global = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / F4R, c4 = f % F4R;
+            const int pk = k0 + row;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (pk < k_end) {
+                const int bi = pk / per;
+                const int rem = pk - bi * per;
+                const int y = rem / p.w, x = rem - y * p.w;
+                const int ca = m0 + c4 * 4, cb = n0 + c4 * 4;
+                if (MODE == WG_CONVT) {
+                    const int oy = 2 * y + (tap >> 1) + p.off_y, ox = 2 * x + (tap & 1) + p.off_x;
+                    if (ca < p.m_total && oy >= 0 && oy < p.a_h && ox >= 0 && ox < p.a_w)
+                        va = *reinterpret_cast<const f32x4*>(p.a + ((static_cast<int64_t>(bi) * p.a_h + oy) * p.a_w + ox) * p.lda + ca);
+                    if (cb < p.n_total) vb = *reinterpret_cast<const f32x4*>(p.b + static_cast<int64_t>(pk) * p.ldb + cb);
+                } else {
+                    if (ca < p.m_total) va = *reinterpret_cast<const f32x4*>(p.a + static_cast<int64_t>(pk) * p.lda + ca);
+                    const int yy = y + dy, xx = x + dx;
+                    if (cb < p.n_total && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w)
+                        vb = *reinterpret_cast<const f32x4*>(p.b + (static_cast<int64_t>(pk) + dy * p.w + dx) * p.ldb + cb);
+                }
+            }
+            areg[i] = va;
+            breg[i] = vb;
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int f = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(&sA[buf][f * 4]) = areg[i];   // [row][c4*4] with row stride BT == f*4
+            *reinterpret_cast<f32x4*>(&sB[buf][f * 4]) = breg[i];
+        }
+    };
+
+    const int steps = (k_end - k_begin + BKP - 1) / BKP;
+    if (steps > 0) {
+        load_global(k_begin);
+        store_lds(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        const bool more = s + 1 < steps;
+        if (more) load_global(k_begin + (s + 1) * BKP);
+        const float* pa = &sA[buf][wm * (BT / 2) + r];
+        const float* pb = &sB[buf][wn * (BT / 2) + r];
+#pragma unroll
+        for (int ks = 0; ks < BKP / 2; ++ks) {
+            const int k = 2 * ks + h;
+            float a[TT], b[TT];
+#pragma unroll
+            for (int i = 0; i < TT; ++i) a[i] = pa[k * BT + i * 32];
+#pragma unroll
+            for (int j = 0; j < TT; ++j) b[j] = pb[k * BT + j * 32];
+#pragma unroll
+            for (int i = 0; i < TT; ++i)
+#pragma unroll
+                for (int j = 0; j < TT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* outp = p.out + static_cast<int64_t>(tap) * p.m_total * p.n_total;
+#pragma unroll
+    for (int j = 0; j < TT; ++j) {
+        const int n = n0 + wn * (BT / 2) + j * 32 + r;
+        if (n >= p.n_total) continue;
+#pragma unroll
+        for (int i = 0; i < TT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BT / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < p.m_total) atomicAdd(outp + static_cast<int64_t>(m) * p.n_total + n, acc[i][j][e]);
+            }
+    }
+}
+
+template <int MODE>
+int launch_wgrad(WgradParams& p, hipStream_t s) {
+    const bool big = p.m_total > 64 || p.n_total > 64;
+    const int bt = big ? 128 : 64;
+    p.m_tiles = (p.m_total + bt - 1) / bt;
+    p.n_tiles = (p.n_total + bt - 1) / bt;
+    const int64_t tiles = static_cast<int64_t>(p.m_tiles) * p.n_tiles * p.taps;
+    // enough pixel splits for ~4 workgroups per CU, at least 8 K-steps (256 pixels) each
+    int64_t splits = (1024 + tiles - 1) / tiles;
+    const int64_t max_splits = (p.k_total + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int64_t chunk = (p.k_total + splits - 1) / splits;
+    chunk = (chunk + BKP - 1) / BKP * BKP;
+    splits = (p.k_total + chunk - 1) / chunk;
+    p.k_chunk = static_cast<int>(chunk);
+    p.splits = static_cast<int>(splits);
+    const int64_t grid = tiles * splits;
+    if (grid > 0x7fffffffll) return ddpm::fail_invalid("wgrad grid size");
+    hipError_t e = hipMemsetAsync(p.out, 0, sizeof(float) * static_cast<size_t>(p.taps) * p.m_total * p.n_total, s);
+    if (e != hipSuccess) {
+        ddpm::set_error("hipMemsetAsync: %s", hipGetErrorString(e));
+        return DDPM_E_LAUNCH;
+    }
+    if (big)
+        conv_wgrad_kernel<128, MODE><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
+    else
+        conv_wgrad_kernel<64, MODE><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
+    return ddpm::check_launch("conv_wgrad_kernel");
+}
+
+// packed [taps][m][n] -> torch parameter layouts
+__global__ void unpack_conv_kernel(const float* __restrict__ packed, int taps, int m, int n, float* __restrict__ out) {
+    // out[m][n][tap]  (Conv2d weight [cout][cin][kh][kw])
+    const int64_t total = static_cast<int64_t>(taps) * m * n;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int tap = static_cast<int>(i % taps);
+        const int64_t mn = i / taps;
+        out[i] = packed[static_cast<int64_t>(tap) * m * n + mn];
+    }
+}
+
+__global__ void unpack_convT_kernel(const float* __restrict__ packed, int m /*cout*/, int n /*cin*/, float* __restrict__ out) {
+    // out[ci][co][q]  (ConvTranspose2d weight [cin][cout][2][2]) from packed[q][co][ci]
+    const int64_t total = static_cast<int64_t>(4) * m * n;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int q = static_cast<int>(i % 4);
+        const int co = static_cast<int>((i / 4) % m);
+        const int ci = static_cast<int>(i / (4ll * m));
+        out[i] = packed[(static_cast<int64_t>(q) * m + co) * n + ci];
+    }
+}
+
+int validate(const float* dy, int lda, int m, const float* x, int ldb, int n, float* packed, float* grad) {
+    DDPM_REQUIRE(dy && x && packed && grad && m > 0 && n > 0);
+    DDPM_REQUIRE((m & 3) == 0 && (n & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && lda >= m && ldb >= n);
+    DDPM_REQUIRE(ddpm::aligned16(dy) && ddpm::aligned16(x) && ddpm::aligned16(packed));
+    return DDPM_OK;
+}
+
+int grid_1d(int64_t total) { return static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256); }
+
+}  // namespace
+
+extern "C" int ddpm_conv3x3_wgrad(const float* dy, int ldy, int cout, const float* x, int ldx, int cin, int batch, int h, int w,
+                                  float* packed, float* grad_w, void* stream) {
+    if (int rc = validate(dy, ldy, cout, x, ldx, cin, packed, grad_w)) return rc;
+    DDPM_REQUIRE(batch > 0 && h > 0 && w > 0 && static_cast<int64_t>(batch) * h * w < (1ll << 31));
+    WgradParams p{};
+    p.a = dy; p.b = x; p.out = packed;
+    p.batch = batch; p.h = h; p.w = w; p.a_h = h; p.a_w = w;
+    p.m_total = cout; p.lda = ldy; p.n_total = cin; p.ldb = ldx;
+    p.taps = 9; p.k_total = batch * h * w;
+    if (int rc = launch_wgrad<WG_CONV3>(p, as_stream(stream))) return rc;
+    unpack_conv_kernel<<<grid_1d(9ll * cout * cin), 256, 0, as_stream(stream)>>>(packed, 9, cout, cin, grad_w);
+    return ddpm::check_launch("unpack_conv_kernel");
+}
+
+extern "C" int ddpm_conv1x1_wgrad(const float* dy, int ldy, int cout, const float* x, int ldx, int cin, int64_t rows, float* grad_w,
+                                  void* stream) {
+    if (int rc = validate(dy, ldy, cout, x, ldx, cin, grad_w, grad_w)) return rc;
+    DDPM_REQUIRE(rows > 0 && rows < (1ll << 31));
+    WgradParams p{};
+    p.a = dy; p.b = x; p.out = grad_w;      // [cout][cin] is already the parameter layout
+    p.batch = 1; p.h = static_cast<int>(rows); p.w = 1; p.a_h = p.h; p.a_w = 1;
+    p.m_total = cout; p.lda = ldy; p.n_total = cin; p.ldb = ldx;
+    p.taps = 1; p.k_total = static_cast<int>(rows);
+    return launch_wgrad<WG_CONV1>(p, as_stream(stream));
+}
+
+// dy: gradient w.r.t. the padded/cropped output image [batch][out_h][out_w] (channels cout, stride ldy);
+// x: the transposed conv's input [batch][h][w] (cin channels). grad_w: [cin][cout][2][2].
+extern "C" int ddpm_convT2x2_wgrad(const float* dy, int ldy, int cout, int out_h, int out_w, int off_y, int off_x, const float* x,
+                                   int ldx, int cin, int batch, int h, int w, float* packed, float* grad_w, void* stream) {
+    if (int rc = validate(dy, ldy, cout, x, ldx, cin, packed, grad_w)) return rc;
+    DDPM_REQUIRE(batch > 0 && h > 0 && w > 0 && out_h > 0 && out_w > 0);
+    DDPM_REQUIRE(static_cast<int64_t>(batch) * h * w < (1ll << 31) && static_cast<int64_t>(batch) * out_h * out_w < (1ll << 31));
+    WgradParams p{};
+    p.a = dy; p.b = x; p.out = packed;
+    p.batch = batch; p.h = h; p.w = w; p.a_h = out_h; p.a_w = out_w;
+    p.m_total = cout; p.lda = ldy; p.n_total = cin; p.ldb = ldx;
+    p.off_y = off_y; p.off_x = off_x;
+    p.taps = 4; p.k_total = batch * h * w;
+    if (int rc = launch_wgrad<WG_CONVT>(p, as_stream(stream))) return rc;
+    unpack_convT_kernel<<<grid_1d(4ll * cout * cin), 256, 0, as_stream(stream)>>>(packed, cout, cin, grad_w);
+    return ddpm::check_launch("unpack_convT_kernel");
+}

@@ -213,6 +213,109 @@ int ddpm_attention_fwd(const float* qkv, const float* x, int ldx, const float* g
                        int ldo, float* attn_raw, float* lse, const float* temb, int batch, int n, int c,
                        int dq, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Train-mode BatchNorm2d (+ activation / residual / time-embedding add), forward and backward.
+ * Replaces nn.BatchNorm2d in training mode together with the ReLU/GELU, the residual add of
+ * ResidualBlock and the `+ time_emb` that follow it: first-iteration/unet.py:17-21,
+ * second-iteration/unet.py:17-26,33-36. Every reduction over (batch, pixels) accumulates in
+ * float64 in a fixed order. `workspace`: ddpm_reduce_workspace_doubles(c) doubles of scratch.
+ * ------------------------------------------------------------------------------------- */
+int64_t ddpm_reduce_workspace_doubles(int c);
+
+/* mean[c], invstd[c] = 1/sqrt(biased var + eps) over `rows` pixels; when running_mean/var are
+ * given they are updated in place: r = (1-momentum)*r + momentum*stat (unbiased variance). */
+int ddpm_bn_stats(const float* x, int ldx, int64_t rows, int c, float eps, float momentum,
+                  double* workspace, float* mean, float* invstd, float* running_mean,
+                  float* running_var, void* stream);
+
+/* out = act((x-mean)*invstd*w + b [+ residual]) [+ temb[b][c]] */
+int ddpm_bn_apply_fwd(const float* x, int ldx, const float* mean, const float* invstd, const float* w,
+                      const float* b, const float* residual, int ldr, const float* temb, int act,
+                      float* out, int ldo, int batch, int hw, int c, void* stream);
+
+/* Backward of the block above given dout = d loss / d out (the embedding add passes gradients
+ * through unchanged). Produces dw, db (written, or added to when accumulate != 0), dx, and
+ * optionally dresidual (= dz) and dconv_bias (= column sums of dx: the gradient of the bias of the
+ * convolution feeding the BatchNorm). sums: scratch of 2*c floats. */
+int ddpm_bn_bwd(const float* x, int ldx, const float* dout, int ldd, const float* residual, int ldr,
+                const float* mean, const float* invstd, const float* w, const float* b, int act,
+                int64_t rows, int c, double* workspace, float* sums, float* dw, float* db,
+                int accumulate, float* dx, int lddx, float* dresidual, int lddr, float* dconv_bias,
+                void* stream);
+
+/* out[g][c] (+)= sum of x over the rows of group g (groups of rows_per_group consecutive pixels):
+ * groups = batch gives the gradient of a broadcast time-embedding add, groups = 1 a bias gradient. */
+int ddpm_colsum(const float* x, int ld, int groups, int64_t rows_per_group, int c, double* workspace,
+                int accumulate, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Backward pass of the convolutions (the gradient of nn.Conv2d / nn.ConvTranspose2d that
+ * loss.backward() computes in first-iteration/main.py:83).
+ *  - data gradient of a 3x3 conv = ddpm_conv3x3_fwd on dY with weights packed by
+ *    ddpm_pack_conv3x3(flip = 1); of a 1x1 conv = ddpm_conv1x1_fwd with the transposed weight.
+ *  - weight gradients are split-K MFMA GEMMs over the pixel axis (fp32 atomics into `packed`,
+ *    scratch of the same size as the weight, then permuted into torch's parameter layout).
+ * ------------------------------------------------------------------------------------- */
+int ddpm_conv3x3_wgrad(const float* dy, int ldy, int cout, const float* x, int ldx, int cin, int batch,
+                       int h, int w, float* packed, float* grad_w /* [cout][cin][3][3] */, void* stream);
+int ddpm_conv1x1_wgrad(const float* dy, int ldy, int cout, const float* x, int ldx, int cin, int64_t rows,
+                       float* grad_w /* [cout][cin] */, void* stream);
+
+/* Transposed conv: dy is the gradient of the padded/cropped output image (out_h x out_w, stride
+ * ldy); x the layer input (h x w). ddpm_convT2x2_dgrad: the in_h/in_w fields give the input geometry, the
+ * out_h/out_w/off_y/off_x fields the output placement, c1/ld1 describe dy, cout = channels of the gradient produced; w_packed from
+ * ddpm_pack_convT2x2_dgrad ([4][cin][cout]). */
+int ddpm_pack_convT2x2_dgrad(const float* w, int cin, int cout, float* out, void* stream);
+int ddpm_convT2x2_dgrad(const ddpm_conv_desc* d, const float* dy, const float* w_packed,
+                        const ddpm_epilogue* ep, float* out, void* stream);
+int ddpm_convT2x2_wgrad(const float* dy, int ldy, int cout, int out_h, int out_w, int off_y, int off_x,
+                        const float* x, int ldx, int cin, int batch, int h, int w, float* packed,
+                        float* grad_w /* [cin][cout][2][2] */, void* stream);
+
+/* First conv (NCHW image in): weight gradient [cout][cin][3][3]; no data gradient is needed. */
+int ddpm_conv3x3_first_wgrad(const float* dy, int ldy, const float* x_nchw, double* workspace, float* dw,
+                             int batch, int cin, int h, int w_, int cout, void* stream);
+
+/* Final 1x1 conv: dout is NCHW; produces dx (NHWC), dw [cout][c], db [cout]. */
+int ddpm_conv1x1_final_bwd(const float* dout_nchw, const float* x, int ldx, const float* w,
+                           double* workspace, float* dx, int lddx, float* dw, float* db, int batch, int h,
+                           int w_, int c, int cout, void* stream);
+
+/* dx = dskip + (dpooled routed to the arg-max position of each 2x2 window): backward of
+ * ddpm_pool_skip_fwd (MaxPool2d + the skip branch), first-iteration/unet.py:33-36. */
+int ddpm_pool_skip_bwd(const float* dskip, int ldds, const float* dpooled, int ldp, const uint8_t* argmax,
+                       float* dx, int lddx, int batch, int h, int w, int c, void* stream);
+
+/* out[c] = sum of x over every sample and the pixel window [y0,y0+win_h) x [x0,x0+win_w): bias
+ * gradient of a transposed conv whose output was padded. */
+int ddpm_colsum_window(const float* x, int ld, int batch, int img_h, int img_w, int y0, int x0, int win_h,
+                       int win_w, int c, double* workspace, float* out, void* stream);
+
+/* Backward of ddpm_time_embed w.r.t. the Linear / Embedding parameters. */
+typedef struct ddpm_embed_bwd_args {
+    int32_t batch, emb_dim, n_labels, reserved;
+    const float* emb;          /* [B][E] saved sinusoidal embedding */
+    const int64_t* y;
+    const float* label_table;
+    int32_t ch[4];
+    const float* dtemb[4];     /* [B][Ck] gradients of the four embedding vectors */
+    const float* lw[4];        /* label Linear weights (forward values) or NULL */
+    float* dw[4];              /* out: time Linear weight grads [Ck][E] */
+    float* db[4];              /* out: time Linear bias grads */
+    float* dlw[4];             /* out: label Linear grads (or NULL) */
+    float* dlb[4];
+    float* dlabel_table;       /* out: [classes][E], zeroed by the caller (rows are added to) */
+} ddpm_embed_bwd_args;
+int ddpm_time_embed_bwd(const ddpm_embed_bwd_args* a, void* stream);
+
+/* Backward of ddpm_attention_fwd given dy = d loss / d out. Produces dqkv [B][N][2*dq+C] (the
+ * gradient of the fused q|k|v projection output) and dgamma; the pass-through term dx += dy is
+ * the caller's. attn_raw/lse: saved by the forward; e_scratch: [B][N] floats;
+ * workspace: >= 1024 doubles. Replaces autograd through second-iteration/unet.py:50-61. */
+int ddpm_attention_bwd(const float* qkv, const float* dy, int ldd, const float* attn_raw, const float* lse,
+                       const float* gamma, double* workspace, float* e_scratch, float* dqkv, float* dgamma,
+                       int batch, int n, int c, int dq, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
