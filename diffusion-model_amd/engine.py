@@ -14,6 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import ConvDesc, EmbedArgs, Epilogue, call
+from .engine_train import TrainMixin, UNetFunction
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 BN_EPS = 1e-5
@@ -57,7 +58,7 @@ class View:
         return self.buf[..., self.c0:self.c0 + self.c].permute(0, 3, 1, 2)
 
 
-class UNetEngine:
+class UNetEngine(TrainMixin):
     def __init__(self, module, variant, in_channels, out_channels, base_channels, embedding_dim, num_classes):
         if base_channels % 4 != 0:
             raise NotImplementedError("base_channels must be a multiple of 4 for the 16-byte vector paths")
@@ -99,9 +100,23 @@ class UNetEngine:
         if x.dtype != torch.float32:
             x = x.float()
         t = t.to(x.device)
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.m.parameters()))
-        if needs_grad or training:
-            raise NotImplementedError("train-mode / differentiable forward is not wired up yet")
+        if y is not None:
+            if self.num_classes is None:
+                raise AttributeError("this UNet was built without num_classes; it has no label embedding")
+            y = y.to(device=x.device, dtype=torch.int64).contiguous()
+        named = list(self.m.named_parameters())
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for _, p in named)
+        if x.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("gradients with respect to the UNet input are not produced (the training loop never asks)")
+        if needs_grad:
+            if not training:
+                raise NotImplementedError("differentiating through eval-mode BatchNorm is not supported; call model.train()")
+            names = tuple(n for n, _ in named)
+            out, *fms = UNetFunction.apply(self, x, t, y, names, *[p for _, p in named])
+            return out, list(fms)
+        if training:
+            out, fms, _ = self.forward_train(x, t, y)
+            return out, fms
         return self.forward_eval(x, t, y)
 
     # ------------------------------------------------------------------ parameters and caches
@@ -209,7 +224,7 @@ class UNetEngine:
         b, h, w = x.bhw
         call("ddpm_add_temb", x.ptr, x.ld, _ptr(temb), out.ptr, out.ld, b, h * w, x.c, _stream())
 
-    def time_embed(self, t, y):
+    def time_embed(self, t, y, emb_out=None):
         B = t.shape[0]
         dev = t.device
         chans = [self.base, self.base * 2, self.base * 4, self.base * 8]
@@ -246,7 +261,7 @@ class UNetEngine:
                 a.lw[k] = self.T(f"label_emdedding_fc{k + 1}.weight").data_ptr()
                 a.lb[k] = self.T(f"label_emdedding_fc{k + 1}.bias").data_ptr()
             a.out[k] = outs[k].data_ptr()
-        a.emb_out = None
+        a.emb_out = emb_out.data_ptr() if emb_out is not None else None
         call("ddpm_time_embed", C.byref(a), _stream())
         return outs
 

@@ -1,0 +1,364 @@
+"""Train-mode forward (batch-statistics BatchNorm, saved activations) and the hand-written backward
+schedule of the UNet, as calls into libddpm_mi355x.so. Mixed into UNetEngine.
+
+The whole network is ONE autograd node (UNetFunction): forward records what the backward needs in
+a plain Python structure, backward walks it in reverse and returns one gradient per parameter, so
+`loss.backward()` / `optim.Adam.step()` of the reference's training loop
+(first-iteration/main.py:76-84) work unchanged.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import ConvDesc, EmbedArgs, EmbedBwdArgs, Epilogue, call, lib
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class TrainMixin:
+    # ------------------------------------------------------------------ scratch
+    def _workspace(self, dev):
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.device != dev:
+            n = lib().ddpm_reduce_workspace_doubles(max(8 * self.base, 64))
+            self._ws = torch.empty(n, dtype=torch.float64, device=dev)
+            self._sums = torch.empty(2 * 8 * self.base, dtype=torch.float32, device=dev)
+        return self._ws
+
+    # ------------------------------------------------------------------ forward pieces
+    def _conv_bn_fwd(self, V, src, conv_key, bn_key, cout, act, out, residual=None, temb=None, first=None):
+        """conv3x3 (+bias) -> batch statistics -> normalise/affine (+residual) -> act (+temb)."""
+        b, h, w = out.bhw
+        dev = out.buf.device
+        raw = V(torch.empty((b, h, w, cout), device=dev, dtype=torch.float32))
+        bias = self.T(conv_key + ".bias")
+        if first is not None:
+            ep = Epilogue(None, _ptr(bias), None, None)
+            call("ddpm_conv3x3_first_fwd", _ptr(first), _ptr(self.T(conv_key + ".weight")), C.byref(ep), ACT_NONE, raw.ptr, b,
+                 first.shape[1], h, w, cout, raw.ld, _stream())
+        else:
+            self.conv3x3(src, self.packed_conv3(conv_key), cout, raw, None, bias)
+        mean = torch.empty(cout, device=dev, dtype=torch.float32)
+        invstd = torch.empty(cout, device=dev, dtype=torch.float32)
+        call("ddpm_bn_stats", raw.ptr, raw.ld, b * h * w, cout, BN_EPS, BN_MOMENTUM, _ptr(self._workspace(dev)), _ptr(mean),
+             _ptr(invstd), _ptr(self.T(bn_key + ".running_mean")), _ptr(self.T(bn_key + ".running_var")), _stream())
+        self.T(bn_key + ".num_batches_tracked").add_(1)
+        call("ddpm_bn_apply_fwd", raw.ptr, raw.ld, _ptr(mean), _ptr(invstd), _ptr(self.T(bn_key + ".weight")),
+             _ptr(self.T(bn_key + ".bias")), residual.ptr if residual is not None else None,
+             residual.ld if residual is not None else 0, _ptr(temb), act, out.ptr, out.ld, b, h * w, cout, _stream())
+        return dict(kind="conv_bn", src=src, raw=raw, mean=mean, invstd=invstd, conv=conv_key, bn=bn_key, act=act,
+                    residual=residual, first=first, cout=cout)
+
+    def _double_conv_fwd(self, V, src, key, cout, out, temb=None, first=None):
+        p = key + ".double_conv"
+        b, h, w = out.bhw
+        dev = out.buf.device
+        act = ACT_RELU if self.v == 1 else ACT_GELU
+        new = lambda: V(torch.empty((b, h, w, cout), device=dev, dtype=torch.float32))
+        a = new()
+        recs = [self._conv_bn_fwd(V, src, p + ".0", p + ".1", cout, act, a, first=first)]
+        if self.v == 1:
+            recs.append(self._conv_bn_fwd(V, a, p + ".3", p + ".4", cout, act, out, temb=temb))
+        else:
+            r = p + ".3.conv_block"
+            m = new()
+            recs.append(self._conv_bn_fwd(V, a, r + ".0", r + ".1", cout, act, m))
+            recs.append(self._conv_bn_fwd(V, m, r + ".3", r + ".4", cout, act, out, residual=a, temb=temb))
+        return recs
+
+    def _attention_fwd_train(self, V, x, key, out, temb=None):
+        save = {}
+        self.attention(x, key, out, temb=temb, save=save)
+        return dict(kind="attn", x=x, key=key, qkv=save["qkv"], raw=save["raw"], lse=save["lse"])
+
+    # ------------------------------------------------------------------ whole network, train mode
+    def forward_train(self, x, t, y=None):
+        from .engine import View as V
+        B, cin, H, W = x.shape
+        if cin != self.cin:
+            raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
+        x = x.contiguous()
+        dev = x.device
+        bc, v1 = self.base, self.v == 1
+        emb = torch.empty((B, self.emb // 2 * 2), device=dev, dtype=torch.float32)
+        temb = self.time_embed(t, y, emb_out=emb)
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        fms = []
+        tape = dict(x=x, t=t, y=y, emb=emb, shape=(B, H, W))
+
+        def buf(h, w, c):
+            return torch.empty((B, h, w, c), device=dev, dtype=torch.float32)
+
+        cat3, cat2, cat1 = buf(H, W, 2 * bc), buf(H, W, 4 * bc), buf(H2, W2, 8 * bc)
+        skip1, skip2, skip3 = V(cat3, 0, bc), V(cat2, 0, 2 * bc), V(cat1, 0, 4 * bc)
+        tape["enc1"] = self._double_conv_fwd(V, None, "enc1", bc, skip1, temb=temb[0], first=x)
+        fms.append(skip1)
+
+        def down(src, key, cout, skip, te, h, w):
+            rec = {}
+            xfull = V(buf(h, w, cout))
+            rec["dc"] = self._double_conv_fwd(V, src, key + ".conv", cout, xfull)
+            if not v1:
+                xa = V(buf(h, w, cout))
+                rec["attn"] = self._attention_fwd_train(V, xfull, key + ".attention", xa)
+                xfull = xa
+            pooled = V(buf(h // 2, w // 2, cout))
+            amax = torch.empty((B, h // 2, w // 2, cout), device=dev, dtype=torch.uint8)
+            call("ddpm_pool_skip_fwd", xfull.ptr, xfull.ld, _ptr(te), skip.ptr, skip.ld, pooled.ptr, pooled.ld, _ptr(amax), B, h, w,
+                 cout, _stream())
+            rec.update(argmax=amax, hw=(h, w), cout=cout)
+            return pooled, rec
+
+        p2, tape["enc2"] = down(skip1, "enc2", 2 * bc, skip2, temb[1], H, W)
+        fms.append(skip2)
+        p3, tape["enc3"] = down(p2, "enc3", 4 * bc, skip3, temb[2], H2, W2)
+        fms.append(skip3)
+
+        def tail(src, key_conv, key_attn, cout, te, h, w):
+            rec = {}
+            if v1:
+                pre = V(buf(h, w, cout))
+                rec["dc"] = self._double_conv_fwd(V, src, key_conv, cout, pre)
+                fms.append(pre)
+                post = V(buf(h, w, cout))
+                self.add_temb(pre, te, post)
+                return post, rec
+            mid = V(buf(h, w, cout))
+            rec["dc"] = self._double_conv_fwd(V, src, key_conv, cout, mid)
+            post = V(buf(h, w, cout))
+            rec["attn"] = self._attention_fwd_train(V, mid, key_attn, post, temb=te)
+            fms.append(post)
+            return post, rec
+
+        hcur, tape["bottleneck"] = tail(p3, "bottleneck" if v1 else "bottleneck.0", "bottleneck.1", 8 * bc, temb[3], H4, W4)
+        for key, cat, cskip, cout, te, (h, w) in (("dec1", cat1, 4 * bc, 4 * bc, temb[2], (H2, W2)),
+                                                   ("dec2", cat2, 2 * bc, 2 * bc, temb[1], (H, W)),
+                                                   ("dec3", cat3, bc, bc, temb[0], (H, W))):
+            up_out = V(cat, cskip, cskip)
+            self.convT(hcur, key + ".up", up_out)
+            up_in = hcur
+            hcur, rec = tail(V(cat), key + ".conv", key + ".attention", cout, te, h, w)
+            rec.update(up_in=up_in, up_out=up_out, cskip=cskip)
+            tape[key] = rec
+
+        out = torch.empty((B, self.cout_final, H, W), device=dev, dtype=torch.float32)
+        call("ddpm_conv1x1_final_fwd", hcur.ptr, hcur.ld, _ptr(self.T("final_conv.weight")), _ptr(self.T("final_conv.bias")),
+             _ptr(out), B, H, W, bc, self.cout_final, _stream())
+        tape["final_in"] = hcur
+        return out, [f.nchw() for f in fms], tape
+
+    # ------------------------------------------------------------------ backward pieces
+    def _conv_bn_bwd(self, V, rec, dout, grads, add=None, need_dsrc=True):
+        """dout: View, gradient of the block's output. Returns the gradient w.r.t. rec['src'] (a View)
+        and the gradient w.r.t. the residual input (a View or None)."""
+        raw, cout = rec["raw"], rec["cout"]
+        b, h, w = raw.bhw
+        dev = raw.buf.device
+        rows = b * h * w
+        ws = self._workspace(dev)
+        draw = V(torch.empty((b, h, w, cout), device=dev, dtype=torch.float32))
+        res = rec["residual"]
+        dres = V(torch.empty((b, h, w, cout), device=dev, dtype=torch.float32)) if res is not None else None
+        bn, conv = rec["bn"], rec["conv"]
+        dw, db, dcb = (torch.empty(cout, device=dev, dtype=torch.float32) for _ in range(3))
+        call("ddpm_bn_bwd", raw.ptr, raw.ld, dout.ptr, dout.ld, res.ptr if res is not None else None, res.ld if res is not None else 0,
+             _ptr(rec["mean"]), _ptr(rec["invstd"]), _ptr(self.T(bn + ".weight")), _ptr(self.T(bn + ".bias")), rec["act"], rows, cout,
+             _ptr(ws), _ptr(self._sums), _ptr(dw), _ptr(db), 0, draw.ptr, draw.ld, dres.ptr if dres is not None else None,
+             dres.ld if dres is not None else 0, _ptr(dcb), _stream())
+        grads[bn + ".weight"], grads[bn + ".bias"], grads[conv + ".bias"] = dw, db, dcb
+        wt = self.T(conv + ".weight")
+        gw = torch.empty_like(wt)
+        if rec["first"] is not None:
+            img = rec["first"]
+            call("ddpm_conv3x3_first_wgrad", draw.ptr, draw.ld, _ptr(img), _ptr(ws), _ptr(gw), b, img.shape[1], h, w, cout, _stream())
+            grads[conv + ".weight"] = gw
+            return None, dres
+        src = rec["src"]
+        packed = torch.empty(wt.numel(), device=dev, dtype=torch.float32)
+        call("ddpm_conv3x3_wgrad", draw.ptr, draw.ld, cout, src.ptr, src.ld, src.c, b, h, w, _ptr(packed), _ptr(gw), _stream())
+        grads[conv + ".weight"] = gw
+        dsrc = None
+        if need_dsrc:
+            dsrc = V(torch.empty((b, h, w, src.c), device=dev, dtype=torch.float32))
+            self.conv3x3(draw, self.packed_conv3(conv, flip=True), src.c, dsrc, residual=add)
+        return dsrc, dres
+
+    def _double_conv_bwd(self, V, recs, dout, grads, add=None, need_dsrc=True):
+        if self.v == 1:
+            d_a, _ = self._conv_bn_bwd(V, recs[1], dout, grads)
+            return self._conv_bn_bwd(V, recs[0], d_a, grads, add=add, need_dsrc=need_dsrc)[0]
+        d_m, d_a_res = self._conv_bn_bwd(V, recs[2], dout, grads)
+        d_a, _ = self._conv_bn_bwd(V, recs[1], d_m, grads, add=d_a_res)
+        return self._conv_bn_bwd(V, recs[0], d_a, grads, add=add, need_dsrc=need_dsrc)[0]
+
+    def _attention_bwd(self, V, rec, dout, grads):
+        x, key, qkv = rec["x"], rec["key"], rec["qkv"]
+        b, h, w = x.bhw
+        c, n = x.c, h * w
+        dev = x.buf.device
+        wq, bq, dqp = self.packed_qkv(key)
+        lq = 2 * dqp + c
+        dq = c // 8
+        dqkv = V(torch.empty((b, h, w, lq), device=dev, dtype=torch.float32))
+        dgamma = torch.empty(1, device=dev, dtype=torch.float32)
+        e = torch.empty((b, n), device=dev, dtype=torch.float32)
+        ws = self._workspace(dev)
+        call("ddpm_attention_bwd", qkv.ptr, dout.ptr, dout.ld, _ptr(rec["raw"]), _ptr(rec["lse"]), _ptr(self.T(key + ".gamma")),
+             _ptr(ws), _ptr(e), dqkv.ptr, _ptr(dgamma), b, n, c, dqp, _stream())
+        grads[key + ".gamma"] = dgamma
+        gw = torch.empty((lq, c), device=dev, dtype=torch.float32)
+        call("ddpm_conv1x1_wgrad", dqkv.ptr, lq, lq, x.ptr, x.ld, c, b * n, _ptr(gw), _stream())
+        gb = torch.empty(lq, device=dev, dtype=torch.float32)
+        call("ddpm_colsum", dqkv.ptr, lq, 1, b * n, lq, _ptr(ws), 0, _ptr(gb), _stream())
+        for name, lo, cnt in (("query", 0, dq), ("key", dqp, dq), ("value", 2 * dqp, c)):
+            grads[f"{key}.{name}.weight"] = gw[lo:lo + cnt].reshape(self.T(f"{key}.{name}.weight").shape)
+            grads[f"{key}.{name}.bias"] = gb[lo:lo + cnt]
+        # dx = dqkv @ Wqkv + dout   (1x1 conv with the transposed weight, residual = pass-through gradient)
+        wt = self._cached("qkvT", tuple(f"{key}.{nm}.{s}" for nm in ("query", "key", "value") for s in ("weight", "bias")),
+                          lambda *ts: self.packed_qkv(key)[0].t().contiguous())
+        dx = V(torch.empty((b, h, w, c), device=dev, dtype=torch.float32))
+        d = ConvDesc(batch=b, in_h=h, in_w=w, c1=lq, ld1=lq, c2=0, ld2=0, cout=c, ldo=c, act=ACT_NONE, ldr=dout.ld, out_h=h, out_w=w,
+                     off_y=0, off_x=0)
+        ep = Epilogue(None, None, dout.ptr, None)
+        self._launch(self._gemm_label("conv1x1", b * n, c), 2.0 * b * n * c * lq, "ddpm_conv1x1_fwd", C.byref(d), dqkv.ptr, None,
+                     _ptr(wt), C.byref(ep), dx.ptr, _stream())
+        return dx
+
+    def _temb_grad(self, dview, dtemb, k, dev):
+        """dtemb[k] (+)= per-sample column sums of the gradient at a `+ time_emb` site."""
+        b, h, w = dview.bhw
+        first = dtemb[k] is None
+        if first:
+            dtemb[k] = torch.empty((b, dview.c), device=dev, dtype=torch.float32)
+        call("ddpm_colsum", dview.ptr, dview.ld, b, h * w, dview.c, _ptr(self._workspace(dev)), 0 if first else 1, _ptr(dtemb[k]),
+             _stream())
+
+    # ------------------------------------------------------------------ whole network backward
+    def backward(self, tape, dout):
+        from .engine import View as V
+        B, H, W = tape["shape"]
+        dev = dout.device
+        bc, v1 = self.base, self.v == 1
+        grads, dtemb = {}, [None, None, None, None]
+        ws = self._workspace(dev)
+        dout = dout.contiguous()
+
+        # final 1x1 conv
+        hfin = tape["final_in"]
+        dh = V(torch.empty((B, H, W, bc), device=dev, dtype=torch.float32))
+        gw = torch.empty_like(self.T("final_conv.weight"))
+        gb = torch.empty_like(self.T("final_conv.bias"))
+        call("ddpm_conv1x1_final_bwd", _ptr(dout), hfin.ptr, hfin.ld, _ptr(self.T("final_conv.weight")), _ptr(ws), dh.ptr, dh.ld,
+             _ptr(gw), _ptr(gb), B, H, W, bc, self.cout_final, _stream())
+        grads["final_conv.weight"], grads["final_conv.bias"] = gw, gb
+
+        def tail_bwd(rec, dpost, k, add=None, need_dsrc=True):
+            self._temb_grad(dpost, dtemb, k, dev)
+            d = dpost
+            if not v1:
+                d = self._attention_bwd(V, rec["attn"], dpost, grads)
+            return self._double_conv_bwd(V, rec["dc"], d, grads, add=add, need_dsrc=need_dsrc)
+
+        dskips = {}
+        for key, k in (("dec3", 0), ("dec2", 1), ("dec1", 2)):
+            rec = tape[key]
+            dcat = tail_bwd(rec, dh, k)                                   # [B,h,w,2*cskip]
+            cs = rec["cskip"]
+            dskips[key] = V(dcat.buf, 0, cs)
+            dup = V(dcat.buf, cs, cs)
+            up_in, up_out = rec["up_in"], rec["up_out"]
+            b, h, w = up_in.bhw
+            _, oh, ow = up_out.bhw
+            off_y, off_x = (oh - 2 * h) // 2, (ow - 2 * w) // 2
+            ukey = key + ".up"
+            wt = self.T(ukey + ".weight")
+            guw, packed = torch.empty_like(wt), torch.empty(wt.numel(), device=dev, dtype=torch.float32)
+            call("ddpm_convT2x2_wgrad", dup.ptr, dup.ld, cs, oh, ow, off_y, off_x, up_in.ptr, up_in.ld, up_in.c, b, h, w, _ptr(packed),
+                 _ptr(guw), _stream())
+            y0, x0 = max(off_y, 0), max(off_x, 0)
+            y1, x1 = min(oh, off_y + 2 * h), min(ow, off_x + 2 * w)
+            gub = torch.empty(cs, device=dev, dtype=torch.float32)
+            call("ddpm_colsum_window", dup.ptr, dup.ld, b, oh, ow, y0, x0, y1 - y0, x1 - x0, cs, _ptr(ws), _ptr(gub), _stream())
+            grads[ukey + ".weight"], grads[ukey + ".bias"] = guw, gub
+            dh = V(torch.empty((b, h, w, up_in.c), device=dev, dtype=torch.float32))
+            d = ConvDesc(batch=b, in_h=h, in_w=w, c1=cs, ld1=dup.ld, c2=0, ld2=0, cout=up_in.c, ldo=dh.ld, act=ACT_NONE, ldr=0,
+                         out_h=oh, out_w=ow, off_y=off_y, off_x=off_x)
+            ep = Epilogue(None, None, None, None)
+            wpk = self._cached("pkTd", (ukey + ".weight",), lambda wt_: self._pack_convT_dgrad(wt_))
+            call("ddpm_convT2x2_dgrad", C.byref(d), dup.ptr, _ptr(wpk), C.byref(ep), dh.ptr, _stream())
+
+        dp3 = tail_bwd(tape["bottleneck"], dh, 3)                          # gradient of enc3's pooled output
+
+        def down_bwd(rec, dskip, dpooled, k, add=None):
+            self._temb_grad(dskip, dtemb, k, dev)
+            h, w = rec["hw"]
+            cout = rec["cout"]
+            dx = V(torch.empty((B, h, w, cout), device=dev, dtype=torch.float32))
+            call("ddpm_pool_skip_bwd", dskip.ptr, dskip.ld, dpooled.ptr, dpooled.ld, _ptr(rec["argmax"]), dx.ptr, dx.ld, B, h, w, cout,
+                 _stream())
+            if not v1:
+                dx = self._attention_bwd(V, rec["attn"], dx, grads)
+            return self._double_conv_bwd(V, rec["dc"], dx, grads, add=add)
+
+        dp2 = down_bwd(tape["enc3"], dskips["dec1"], dp3, 2)
+        dskip1 = down_bwd(tape["enc2"], dskips["dec2"], dp2, 1, add=dskips["dec3"])   # total gradient of skip1
+        self._temb_grad(dskip1, dtemb, 0, dev)
+        self._double_conv_bwd(V, tape["enc1"], dskip1, grads, need_dsrc=False)
+
+        # time / label embedding Linears
+        y = tape["y"]
+        chans = [bc, 2 * bc, 4 * bc, 8 * bc]
+        g = EmbedBwdArgs()
+        g.batch, g.emb_dim, g.n_labels = B, self.emb, (0 if y is None else y.numel())
+        g.emb = tape["emb"].data_ptr()
+        outs = {}
+        if y is not None:
+            g.y = y.data_ptr()
+            g.label_table = self.T("label_embedding.weight").data_ptr()
+            outs["label_embedding.weight"] = torch.zeros_like(self.T("label_embedding.weight"))
+            g.dlabel_table = outs["label_embedding.weight"].data_ptr()
+        for k in range(4):
+            g.ch[k] = chans[k]
+            g.dtemb[k] = dtemb[k].data_ptr()
+            for nm, field in ((f"time_fc{k + 1}.weight", g.dw), (f"time_fc{k + 1}.bias", g.db)):
+                outs[nm] = torch.empty_like(self.T(nm))
+                field[k] = outs[nm].data_ptr()
+            if y is not None:
+                g.lw[k] = self.T(f"label_emdedding_fc{k + 1}.weight").data_ptr()
+                for nm, field in ((f"label_emdedding_fc{k + 1}.weight", g.dlw), (f"label_emdedding_fc{k + 1}.bias", g.dlb)):
+                    outs[nm] = torch.empty_like(self.T(nm))
+                    field[k] = outs[nm].data_ptr()
+        call("ddpm_time_embed_bwd", C.byref(g), _stream())
+        grads.update(outs)
+        return grads
+
+    def _pack_convT_dgrad(self, wt):
+        out = torch.empty(wt.numel(), device=wt.device, dtype=torch.float32)
+        call("ddpm_pack_convT2x2_dgrad", _ptr(wt.detach().contiguous()), wt.shape[0], wt.shape[1], _ptr(out), _stream())
+        return out
+
+
+class UNetFunction(torch.autograd.Function):
+    """The whole UNet as one autograd node. Inputs after `engine` are (x, t, y, *parameters)."""
+
+    @staticmethod
+    def forward(ctx, engine, x, t, y, names, *params):
+        out, fms, tape = engine.forward_train(x, t, y)
+        ctx.engine, ctx.tape, ctx.names = engine, tape, names
+        ctx.mark_non_differentiable(*fms)
+        return (out, *fms)
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        grads = ctx.engine.backward(ctx.tape, dout)
+        ctx.tape = None
+        return (None, None, None, None, None, *[grads.get(n) for n in ctx.names])
