@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 """Benchmark of the DDPM hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload sample|train] [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--workload train|sample] [--batch B]
 
 One "step" is one pass of the hot path over one batch of synthetic input:
-  sample : one ancestral denoising step at batch B per GPU (UNet eval forward, noise draw, fused
-           reverse-step kernel). The metric, sampled images/sec over the full T=1000-step loop, is
-           B_total / (1000 * seconds per step).
-  train  : one training step (noise, forward noising, UNet train forward, eps-MSE, backward, Adam).
-For N > 1 the batch axis is sharded: every rank runs the same step on its own B (weak scaling), with
-no data-path collective for sampling and an RCCL gradient all-reduce for training.
+  train  (default; BASELINE.json configs[1]): the body of the reference's training loop
+         (first-iteration/main.py:65-87) -- noise + timestep draw, forward noising, UNet train-mode
+         forward, eps-MSE, backward, Adam step, loss.item() -- second-iteration UNet (1,1,64,128),
+         1x28x28, batch 256 per GPU. value = train samples/s.
+  sample (BASELINE.json configs[2]): one ancestral denoising step at batch B per GPU (UNet eval
+         forward, noise draw, fused reverse-step kernel), third-iteration UNet, 1x32x32. The metric,
+         sampled images/s over the full T=1000-step loop, is B_total / (1000 * seconds per step).
+For N > 1 the batch axis is sharded (weak scaling: per-GPU batch fixed): no data-path collective for
+sampling; an RCCL all-reduce (average) of the flattened gradients per training step.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -28,13 +32,13 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
 FP32_MFMA_PEAK_TFLOPS = 157.3     # gfx950 dense fp32 matrix peak
 T_FULL = 1000
 
-# forward GFLOP per sample of one UNet call (2 x MAC, conv + convT + attention matmuls)
 WORKLOADS = {
-    "sample": dict(name="C3: third-iteration UNet (1,1,64,128,num_classes=10), 1x32x32, full T=1000 ancestral sampling, "
-                        "batch 4096 sharded over the GPUs (512 per GPU per step here)",
-                   variant=3, cin=1, hw=32, batch=512, labels=True),
-    "train": dict(name="C2: second-iteration UNet (1,1,64,128), 1x28x28, batch 256 training step", variant=2, cin=1, hw=28,
-                  batch=256, labels=False),
+    "train": dict(name="configs[1]: second-iteration UNet (1,1,64,128), MNIST-shaped 1x28x28, batch 256 training step "
+                       "(noise, add_noise, fwd, eps-MSE, bwd, Adam)", variant=2, cin=1, hw=28, batch=256, labels=False,
+                  metric="train samples/sec", unit="samples/s"),
+    "sample": dict(name="configs[2]: third-iteration UNet (1,1,64,128,num_classes=10), 1x32x32, full T=1000 ancestral sampling, "
+                        "batch 4096 sharded over 8 GPUs (512 per GPU)", variant=3, cin=1, hw=32, batch=512, labels=True,
+                   metric="sampled images/sec (full T-step loop)", unit="images/s"),
 }
 
 
@@ -48,30 +52,42 @@ def build_model(variant, cin, labels):
     return m
 
 
-def cpu_baseline_sample(variant, cin, hw, labels, seconds=12.0):
-    """Oracle (CPU restatement) timed on the host cores for the same denoising step, bounded sample."""
+def cpu_baseline(workload, wl, seconds=12.0):
+    """The CPU oracle (a torch-CPU restatement of the reference) timed on the host cores, bounded sample."""
     from oracle import ddpm_oracle as O
-    from seeding import seeded_state_dict
-    m = build_model(variant, cin, labels)
+    m = build_model(wl["variant"], wl["cin"], wl["labels"])
     sd = {k: v.clone() for k, v in m.state_dict().items()}
-    B = 8
-    x = torch.randn(B, cin, hw, hw)
-    t = torch.full((B,), 500, dtype=torch.long)
-    y = torch.tensor([3]) if labels else None
     betas = O.schedule_betas("linear", T_FULL)
     alphas, abar = O.schedule_tables(betas)
-    c = O.step_coefficients(betas, alphas, abar, 500)
+    B, cin, hw = 8, wl["cin"], wl["hw"]
     n, t0 = 0, time.time()
-    with torch.no_grad():
-        while True:
-            eps = O.unet_forward(sd, variant, x, t, y, train=False)[0]
-            x = torch.from_numpy(O.reverse_step(x.numpy(), eps.numpy(), torch.randn_like(x).numpy(), *c))
-            n += 1
-            if time.time() - t0 > seconds and n >= 2:
-                break
+    if workload == "sample":
+        x = torch.randn(B, cin, hw, hw)
+        t = torch.full((B,), 500, dtype=torch.long)
+        y = torch.tensor([3]) if wl["labels"] else None
+        c = O.step_coefficients(betas, alphas, abar, 500)
+        with torch.no_grad():
+            while n < 2 or time.time() - t0 < seconds:
+                eps = O.unet_forward(sd, wl["variant"], x, t, y, train=False)[0]
+                x = torch.from_numpy(O.reverse_step(x.numpy(), eps.numpy(), torch.randn_like(x).numpy(), *c))
+                n += 1
+        dt = (time.time() - t0) / n
+        return dict(value=B / (T_FULL * dt), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                    sample=f"{n} denoising steps of the CPU oracle at batch {B}, extrapolated to the {T_FULL}-step loop")
+    params = {k: v.clone() for k, v in sd.items() if O.is_param(k)}
+    state, cur = {}, dict(sd)
+    while n < 2 or time.time() - t0 < seconds:
+        x0, noise = torch.rand(B, cin, hw, hw) * 2 - 1, torch.randn(B, cin, hw, hw)
+        t = torch.randint(0, T_FULL, (B,))
+        noisy = torch.from_numpy(O.add_noise(x0.numpy(), noise.numpy(), t.numpy(), abar))
+        cur.update(params)
+        _, grads, _, bufs = O.loss_and_grads(cur, wl["variant"], noisy, t, noise)
+        cur.update(bufs)
+        O.adam_step(params, grads, state)
+        n += 1
     dt = (time.time() - t0) / n
-    return dict(value=B / (T_FULL * dt), unit="images/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} denoising steps of the CPU oracle at batch {B}, extrapolated to the {T_FULL}-step loop")
+    return dict(value=B / dt, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} training steps of the CPU oracle (torch-CPU autograd + Adam) at batch {B}")
 
 
 def main():
@@ -79,7 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="sample", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="train", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -87,9 +103,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world == 1 and args.gpus > 1:
+        sys.exit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -99,30 +114,62 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import diffusion_model_amd as pkg
+    from diffusion_model_amd._lib import call
     from diffusion_model_amd.schedule import step_coefficients_host
     wl = WORKLOADS[args.workload]
-    if args.workload != "sample":
-        sys.exit("train workload is not available yet")
     B = args.batch or wl["batch"]
-    model = build_model(wl["variant"], wl["cin"], wl["labels"]).to(dev).eval()
+    shape = (B, wl["cin"], wl["hw"], wl["hw"])
+    model = build_model(wl["variant"], wl["cin"], wl["labels"]).to(dev)
     betas = pkg.BetaScheduler(T_FULL, device=dev).get_schedule("linear")
     dm = pkg.make_diffusion_class(wl["variant"])(model, betas, T_FULL)
-    labels = torch.tensor([3], device=dev) if wl["labels"] else None
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    x = torch.randn((B, wl["cin"], wl["hw"], wl["hw"]), generator=g).to(dev)
-    import ctypes as C
-    from diffusion_model_amd._lib import call
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
 
-    def one_step(x, t):
-        """Body of the sampling loop for timestep t (third-iteration/diffusion.py:24-44)."""
-        tt = torch.full((B,), t, dtype=torch.long, device=dev)
-        eps = model(x, tt, labels) if wl["variant"] == 3 else model(x, tt)
-        c1, c2, c3 = step_coefficients_host(dm._betas_h[t], dm._alphas_h[t], dm._abar_h[t])
-        z = torch.randn_like(x)
-        out = torch.empty_like(x)
-        call("ddpm_reverse_step", C.c_void_p(x.data_ptr()), C.c_void_p(eps.data_ptr()), None, 0.0, C.c_void_p(z.data_ptr()),
-             c1, c2, c3, C.c_void_p(out.data_ptr()), x.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        return out
+    if args.workload == "sample":
+        model.eval()
+        labels = torch.tensor([3], device=dev) if wl["labels"] else None
+        state = {"x": torch.randn(shape, generator=gen).to(dev), "t": T_FULL - 1}
+
+        def one_step():
+            """Body of the sampling loop for one timestep (third-iteration/diffusion.py:24-44)."""
+            x, t = state["x"], state["t"]
+            with torch.no_grad():
+                tt = torch.full((B,), t, dtype=torch.long, device=dev)
+                eps = model(x, tt, labels) if wl["variant"] == 3 else model(x, tt)
+                c1, c2, c3 = step_coefficients_host(dm._betas_h[t], dm._alphas_h[t], dm._abar_h[t])
+                z = torch.randn_like(x)
+                out = torch.empty_like(x)
+                call("ddpm_reverse_step", C.c_void_p(x.data_ptr()), C.c_void_p(eps.data_ptr()), None, 0.0, C.c_void_p(z.data_ptr()),
+                     c1, c2, c3, C.c_void_p(out.data_ptr()), x.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            state["x"], state["t"] = out, t - 1
+    else:
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=2e-4)
+        crit = torch.nn.MSELoss()
+        data = (torch.rand(shape, generator=gen) * 2 - 1).to(dev)            # synthetic MNIST-shaped batch in [-1, 1]
+        params = [p for p in model.parameters()]
+        state = {"loss": 0.0}
+
+        def one_step():
+            """Body of the reference's training loop (first-iteration/main.py:65-87)."""
+            x = data
+            noise = torch.randn_like(x)
+            timesteps = torch.randint(0, T_FULL, (B,), device=dev)
+            noisy = dm.add_noise(x, noise, timesteps)
+            pred = model(noisy, timesteps)
+            loss = crit(pred, noise)
+            opt.zero_grad()
+            loss.backward()
+            if dist is not None:                                             # data-parallel: average gradients over ranks
+                gs = [p.grad for p in params if p.grad is not None]
+                flat = torch.cat([g.reshape(-1) for g in gs])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat.div_(world)
+                off = 0
+                for g in gs:
+                    g.copy_(flat[off:off + g.numel()].view_as(g))
+                    off += g.numel()
+            opt.step()
+            state["loss"] = loss.item()
 
     def barrier():
         torch.cuda.synchronize()
@@ -130,29 +177,28 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    with torch.no_grad():
-        t = T_FULL - 1
-        for _ in range(args.warmup):
-            x = one_step(x, t)
-            t -= 1
-        model._engine.prof = []
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            x = one_step(x, t)
-            t -= 1
-        barrier()
-        dt = time.perf_counter() - t0
+    for _ in range(args.warmup):
+        one_step()
+    model._engine.prof = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
     prof = model._engine.prof
     model._engine.prof = None
-    assert torch.isfinite(x).all()
+    if args.workload == "sample":
+        assert torch.isfinite(state["x"]).all()
+    else:
+        assert state["loss"] == state["loss"], "loss is NaN"
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
-    ms_per_step = dt / args.steps * 1e3
+    sec_per_step = dt / args.steps
     total_b = B * world
-    value = total_b / (T_FULL * dt / args.steps)
+    value = total_b / (T_FULL * sec_per_step) if args.workload == "sample" else total_b / sec_per_step
 
     # per-kernel figures from the HIP events recorded around every MFMA launch of the timed steps
     agg = {}
@@ -164,14 +210,20 @@ def main():
     dom = max(agg.items(), key=lambda kv: kv[1][1])
     achieved = dom[1][0] / dom[1][1] / 1e12
     kernels = {k: dict(launches=v[2], avg_ms=round(v[1] / v[2] * 1e3, 4), tflops=round(v[0] / v[1] / 1e12, 2),
-                       share_of_step=round(v[1] / dt, 3)) for k, v in agg.items()}
+                       share_of_step=round(v[1] / dt, 3)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+    cfg = {"workload": wl["name"], "per_gpu_batch": B, "global_batch": total_b}
+    if args.workload == "sample":
+        cfg.update(T=T_FULL, step="one denoising step (UNet eval forward + noise draw + fused reverse-step kernel); "
+                                  "images/s = global_batch / (T * seconds_per_step)")
+    else:
+        cfg.update(optimizer="torch.optim.Adam(lr=2e-4)", batchnorm="per-rank batch statistics",
+                   parallelism=("dp%d: RCCL all-reduce of flattened gradients" % world) if world > 1 else "single GPU",
+                   last_loss=round(state["loss"], 5))
     out = {
-        "metric": "sampled images/sec (full T-step loop)", "value": round(value, 4), "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "metric": wl["metric"], "value": round(value, 4), "unit": wl["unit"],
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wl["name"], "per_gpu_batch": B, "global_batch": total_b, "T": T_FULL,
-                   "step": "one denoising step (UNet eval forward + noise draw + fused reverse-step kernel); "
-                           "images/s = global_batch / (T * seconds_per_step)"},
+        "config": cfg,
         "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                      "avg_launch_ms": round(dom[1][1] / dom[1][2] * 1e3, 4), "launches": dom[1][2]},
@@ -179,7 +231,7 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_sample(wl["variant"], wl["cin"], wl["hw"], wl["labels"])
+            out["cpu_baseline"] = cpu_baseline(args.workload, wl)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

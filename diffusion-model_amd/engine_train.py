@@ -184,7 +184,8 @@ class TrainMixin:
             return None, dres
         src = rec["src"]
         packed = torch.empty(wt.numel(), device=dev, dtype=torch.float32)
-        call("ddpm_conv3x3_wgrad", draw.ptr, draw.ld, cout, src.ptr, src.ld, src.c, b, h, w, _ptr(packed), _ptr(gw), _stream())
+        self._launch("conv_wgrad<conv3x3>", 2.0 * rows * cout * 9 * src.c, "ddpm_conv3x3_wgrad", draw.ptr, draw.ld, cout, src.ptr, src.ld,
+                     src.c, b, h, w, _ptr(packed), _ptr(gw), _stream())
         grads[conv + ".weight"] = gw
         dsrc = None
         if need_dsrc:
@@ -212,11 +213,13 @@ class TrainMixin:
         dgamma = torch.empty(1, device=dev, dtype=torch.float32)
         e = torch.empty((b, n), device=dev, dtype=torch.float32)
         ws = self._workspace(dev)
-        call("ddpm_attention_bwd", qkv.ptr, dout.ptr, dout.ld, _ptr(rec["raw"]), _ptr(rec["lse"]), _ptr(self.T(key + ".gamma")),
-             _ptr(ws), _ptr(e), dqkv.ptr, _ptr(dgamma), b, n, c, dqp, _stream())
+        self._launch("attention_bwd", 2.0 * b * n * n * (2 * dqp + 2 * c + dqp + c), "ddpm_attention_bwd", qkv.ptr, dout.ptr, dout.ld,
+                     _ptr(rec["raw"]), _ptr(rec["lse"]), _ptr(self.T(key + ".gamma")), _ptr(ws), _ptr(e), dqkv.ptr, _ptr(dgamma), b, n, c,
+                     dqp, _stream())
         grads[key + ".gamma"] = dgamma
         gw = torch.empty((lq, c), device=dev, dtype=torch.float32)
-        call("ddpm_conv1x1_wgrad", dqkv.ptr, lq, lq, x.ptr, x.ld, c, b * n, _ptr(gw), _stream())
+        self._launch("conv_wgrad<conv1x1>", 2.0 * b * n * lq * c, "ddpm_conv1x1_wgrad", dqkv.ptr, lq, lq, x.ptr, x.ld, c, b * n, _ptr(gw),
+                     _stream())
         gb = torch.empty(lq, device=dev, dtype=torch.float32)
         call("ddpm_colsum", dqkv.ptr, lq, 1, b * n, lq, _ptr(ws), 0, _ptr(gb), _stream())
         for name, lo, cnt in (("query", 0, dq), ("key", dqp, dq), ("value", 2 * dqp, c)):
