@@ -36,6 +36,25 @@ __device__ __forceinline__ void block_reduce8(double v[8], const Lanes& l, doubl
     }
 }
 
+
+// Deterministic finishing sum: a 256-thread workgroup finishes 16 consecutive outputs; thread
+// (li = tid & 15, sl = tid >> 4) adds every 16th partial, the 16 slices are then added in order.
+// Returns the total in the threads with sl == 0.
+__device__ __forceinline__ double sliced_sum(const double* __restrict__ partial, int nblk, int64_t stride, int64_t offset, bool valid,
+                                             double* sh /* [256] */) {
+    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    double acc = 0.0;
+    if (valid)
+        for (int b = sl; b < nblk; b += 16) acc += partial[static_cast<int64_t>(b) * stride + offset];
+    __syncthreads();
+    sh[sl * 16 + li] = acc;
+    __syncthreads();
+    double tot = 0.0;
+    if (sl == 0)
+        for (int k = 0; k < 16; ++k) tot += sh[k * 16 + li];
+    return tot;
+}
+
 int blocks_for(int64_t rows, int c) {
     const int rpp = kThreads / (c / 4) > 0 ? kThreads / (c / 4) : 1;
     int64_t nb = (rows + static_cast<int64_t>(rpp) * 8 - 1) / (static_cast<int64_t>(rpp) * 8);
@@ -129,12 +148,13 @@ __global__ __launch_bounds__(kThreads) void final_bwd_weight_partial_kernel(cons
     }
 }
 
-__global__ void final_bwd_weight_final_kernel(const double* __restrict__ partial, int nblk, int c, int co, float* __restrict__ dw,
-                                              float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > c) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[static_cast<int64_t>(b) * (c + 4) + i];
+__global__ __launch_bounds__(kThreads) void final_bwd_weight_final_kernel(const double* __restrict__ partial, int nblk, int c, int co,
+                                                                           float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ double sh[kThreads];
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15);        // i == c is the bias slot
+    const bool valid = i <= c;
+    const double s = sliced_sum(partial, nblk, c + 4, i, valid, sh);
+    if ((threadIdx.x >> 4) != 0 || !valid) return;
     if (i < c) dw[static_cast<int64_t>(co) * c + i] = static_cast<float>(s);
     else db[co] = static_cast<float>(s);
 }
@@ -183,13 +203,15 @@ __global__ __launch_bounds__(kThreads) void first_wgrad_partial_kernel(const flo
     }
 }
 
-__global__ void first_wgrad_final_kernel(const double* __restrict__ partial, int nblk, int cin, int ci, int c, float* __restrict__ dw) {
+__global__ __launch_bounds__(kThreads) void first_wgrad_final_kernel(const double* __restrict__ partial, int nblk, int cin, int ci, int c,
+                                                                      float* __restrict__ dw) {
     // dw[co][ci][tap]
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 9 * c) return;
+    __shared__ double sh[kThreads];
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool valid = i < 9 * c;
+    const double s = sliced_sum(partial, nblk, 9 * static_cast<int64_t>(c), i, valid, sh);
+    if ((threadIdx.x >> 4) != 0 || !valid) return;
     const int tap = i / c, co = i % c;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(static_cast<int64_t>(b) * 9 + tap) * c + co];
     dw[(static_cast<int64_t>(co) * cin + ci) * 9 + tap] = static_cast<float>(s);
 }
 
@@ -219,12 +241,12 @@ __global__ __launch_bounds__(kThreads) void colsum_window_partial_kernel(const f
     }
 }
 
-__global__ void vec_final_kernel(const double* __restrict__ partial, int nblk, int c, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[static_cast<int64_t>(b) * c + i];
-    out[i] = static_cast<float>(s);
+__global__ __launch_bounds__(kThreads) void vec_final_kernel(const double* __restrict__ partial, int nblk, int c, float* __restrict__ out) {
+    __shared__ double sh[kThreads];
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool valid = i < c;
+    const double s = sliced_sum(partial, nblk, c, i, valid, sh);
+    if ((threadIdx.x >> 4) == 0 && valid) out[i] = static_cast<float>(s);
 }
 
 // ---- time / label embedding Linears backward -------------------------------------------------
@@ -314,7 +336,7 @@ extern "C" int ddpm_conv1x1_final_bwd(const float* dout_nchw, const float* x, in
     const int nb = blocks_for(static_cast<int64_t>(batch) * hw, c);
     for (int co = 0; co < cout; ++co) {
         final_bwd_weight_partial_kernel<<<nb, kThreads, 0, s>>>(dout_nchw, x, ldx, batch, hw, c, cout, co, workspace);
-        final_bwd_weight_final_kernel<<<(c + 1 + kThreads - 1) / kThreads, kThreads, 0, s>>>(workspace, nb, c, co, dw, db);
+        final_bwd_weight_final_kernel<<<(c + 1 + 15) / 16, kThreads, 0, s>>>(workspace, nb, c, co, dw, db);
     }
     return ddpm::check_launch("conv1x1_final_bwd");
 }
@@ -327,7 +349,7 @@ extern "C" int ddpm_conv3x3_first_wgrad(const float* dy, int ldy, const float* x
     int nb = blocks_for(static_cast<int64_t>(batch) * h * w_, cout);
     for (int ci = 0; ci < cin; ++ci) {
         first_wgrad_partial_kernel<<<nb, kThreads, 0, s>>>(dy, ldy, x_nchw, batch, cin, ci, h, w_, cout, workspace);
-        first_wgrad_final_kernel<<<(9 * cout + kThreads - 1) / kThreads, kThreads, 0, s>>>(workspace, nb, cin, ci, cout, dw);
+        first_wgrad_final_kernel<<<(9 * cout + 15) / 16, kThreads, 0, s>>>(workspace, nb, cin, ci, cout, dw);
     }
     return ddpm::check_launch("conv3x3_first_wgrad");
 }
@@ -339,7 +361,7 @@ extern "C" int ddpm_colsum_window(const float* x, int ld, int batch, int img_h, 
     hipStream_t s = as_stream(stream);
     const int nb = blocks_for(static_cast<int64_t>(batch) * win_h * win_w, c);
     colsum_window_partial_kernel<<<nb, kThreads, 0, s>>>(x, ld, batch, img_h, img_w, y0, x0, win_h, win_w, c, workspace);
-    vec_final_kernel<<<(c + kThreads - 1) / kThreads, kThreads, 0, s>>>(workspace, nb, c, out);
+    vec_final_kernel<<<(c + 15) / 16, kThreads, 0, s>>>(workspace, nb, c, out);
     return ddpm::check_launch("colsum_window");
 }
 

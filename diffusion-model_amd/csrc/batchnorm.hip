@@ -62,6 +62,25 @@ __device__ __forceinline__ void block_reduce8(double v[8], const Lanes& l, doubl
     }
 }
 
+
+// Deterministic finishing sum: a 256-thread workgroup finishes 16 consecutive outputs; thread
+// (li = tid & 15, sl = tid >> 4) adds every 16th partial, the 16 slices are then added in order.
+// Returns the total in the threads with sl == 0.
+__device__ __forceinline__ double sliced_sum(const double* __restrict__ partial, int nblk, int64_t stride, int64_t offset, bool valid,
+                                             double* sh /* [256] */) {
+    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    double acc = 0.0;
+    if (valid)
+        for (int b = sl; b < nblk; b += 16) acc += partial[static_cast<int64_t>(b) * stride + offset];
+    __syncthreads();
+    sh[sl * 16 + li] = acc;
+    __syncthreads();
+    double tot = 0.0;
+    if (sl == 0)
+        for (int k = 0; k < 16; ++k) tot += sh[k * 16 + li];
+    return tot;
+}
+
 // partial[(blk*2 + which)*C + c]
 __global__ __launch_bounds__(kThreads) void bn_stats_partial_kernel(const float* __restrict__ x, int ld, int64_t rows, int c,
                                                                      double* __restrict__ partial) {
@@ -91,13 +110,12 @@ __global__ __launch_bounds__(kThreads) void bn_stats_final_kernel(const double* 
                                                                    float eps, float momentum, float* __restrict__ mean,
                                                                    float* __restrict__ invstd, float* __restrict__ running_mean,
                                                                    float* __restrict__ running_var) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += partial[(static_cast<int64_t>(b) * 2 + 0) * c + ch];
-        ss += partial[(static_cast<int64_t>(b) * 2 + 1) * c + ch];
-    }
+    __shared__ double sh[kThreads];
+    const int ch = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool valid = ch < c;
+    const double s = sliced_sum(partial, nblk, 2 * static_cast<int64_t>(c), ch, valid, sh);
+    const double ss = sliced_sum(partial, nblk, 2 * static_cast<int64_t>(c), c + ch, valid, sh);
+    if ((threadIdx.x >> 4) != 0 || !valid) return;
     const double m = s / static_cast<double>(rows);
     double var = ss / static_cast<double>(rows) - m * m;
     if (var < 0.0) var = 0.0;
@@ -191,13 +209,12 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_partial_kernel(const float* _
 __global__ __launch_bounds__(kThreads) void bn_bwd_final_kernel(const double* __restrict__ partial, int nblk, int c, int accumulate,
                                                                  float* __restrict__ dw, float* __restrict__ db,
                                                                  float* __restrict__ sums) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    double s = 0.0, sx = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += partial[(static_cast<int64_t>(b) * 2 + 0) * c + ch];
-        sx += partial[(static_cast<int64_t>(b) * 2 + 1) * c + ch];
-    }
+    __shared__ double sh[kThreads];
+    const int ch = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool valid = ch < c;
+    const double s = sliced_sum(partial, nblk, 2 * static_cast<int64_t>(c), ch, valid, sh);
+    const double sx = sliced_sum(partial, nblk, 2 * static_cast<int64_t>(c), c + ch, valid, sh);
+    if ((threadIdx.x >> 4) != 0 || !valid) return;
     sums[ch] = static_cast<float>(s);
     sums[c + ch] = static_cast<float>(sx);
     if (accumulate) {
@@ -284,17 +301,17 @@ __global__ __launch_bounds__(kThreads) void colsum_partial_kernel(const float* _
     }
 }
 
+// grid (ceil(c/16), groups)
 __global__ __launch_bounds__(kThreads) void colsum_final_kernel(const double* __restrict__ partial, int groups, int chunks, int c,
                                                                  int accumulate, float* __restrict__ out) {
-    const int64_t total = static_cast<int64_t>(groups) * c;
-    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
-         idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const int ch = static_cast<int>(idx % c);
-        const int64_t g = idx / c;
-        double s = 0.0;
-        for (int k = 0; k < chunks; ++k) s += partial[(g * chunks + k) * c + ch];
-        out[idx] = accumulate ? out[idx] + static_cast<float>(s) : static_cast<float>(s);
-    }
+    __shared__ double sh[kThreads];
+    const int ch = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int64_t g = blockIdx.y;
+    const bool valid = ch < c;
+    const double s = sliced_sum(partial + g * chunks * c, chunks, c, ch, valid, sh);
+    if ((threadIdx.x >> 4) != 0 || !valid) return;
+    const int64_t idx = g * c + ch;
+    out[idx] = accumulate ? out[idx] + static_cast<float>(s) : static_cast<float>(s);
 }
 
 int partial_blocks(int64_t rows, int c) {
@@ -316,7 +333,7 @@ extern "C" int ddpm_bn_stats(const float* x, int ldx, int64_t rows, int c, float
     DDPM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
     const int nb = partial_blocks(rows, c);
     bn_stats_partial_kernel<<<nb, kThreads, 0, as_stream(stream)>>>(x, ldx, rows, c, workspace);
-    bn_stats_final_kernel<<<(c + kThreads - 1) / kThreads, kThreads, 0, as_stream(stream)>>>(workspace, nb, rows, c, eps, momentum, mean,
+    bn_stats_final_kernel<<<(c + 15) / 16, kThreads, 0, as_stream(stream)>>>(workspace, nb, rows, c, eps, momentum, mean,
                                                                                              invstd, running_mean, running_var);
     return ddpm::check_launch("bn_stats");
 }
@@ -353,10 +370,10 @@ extern "C" int ddpm_bn_bwd(const float* x, int ldx, const float* dout, int ldd, 
     hipStream_t s = as_stream(stream);
     const int nb = partial_blocks(rows, c);
     bn_bwd_partial_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, act, rows, c, workspace);
-    bn_bwd_final_kernel<<<(c + kThreads - 1) / kThreads, kThreads, 0, s>>>(workspace, nb, c, accumulate, dw, db, sums);
+    bn_bwd_final_kernel<<<(c + 15) / 16, kThreads, 0, s>>>(workspace, nb, c, accumulate, dw, db, sums);
     bn_bwd_apply_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, sums, act, rows, c, dx, lddx,
                                                 dresidual, lddr, dconv_bias ? workspace : nullptr);
-    if (dconv_bias) colsum_final_kernel<<<(c + kThreads - 1) / kThreads, kThreads, 0, s>>>(workspace, 1, nb, c, accumulate, dconv_bias);
+    if (dconv_bias) colsum_final_kernel<<<dim3((c + 15) / 16, 1), kThreads, 0, s>>>(workspace, 1, nb, c, accumulate, dconv_bias);
     return ddpm::check_launch("bn_bwd");
 }
 
@@ -369,8 +386,6 @@ extern "C" int ddpm_colsum(const float* x, int ld, int groups, int64_t rows_per_
     if (chunks > kMaxColsumBlocks / groups) chunks = kMaxColsumBlocks / groups;
     hipStream_t s = as_stream(stream);
     colsum_partial_kernel<<<groups * chunks, kThreads, 0, s>>>(x, ld, rows_per_group, c, chunks, workspace);
-    const int64_t total = static_cast<int64_t>(groups) * c;
-    colsum_final_kernel<<<static_cast<int>((total + kThreads - 1) / kThreads), kThreads, 0, s>>>(workspace, groups, chunks, c, accumulate,
-                                                                                               out);
+    colsum_final_kernel<<<dim3((c + 15) / 16, groups), kThreads, 0, s>>>(workspace, groups, chunks, c, accumulate, out);
     return ddpm::check_launch("colsum");
 }
