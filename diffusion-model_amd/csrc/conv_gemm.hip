@@ -4,17 +4,28 @@
 //   columns (N) = output channels (x4 sub-positions for the 2x2 transposed conv)
 //   depth   (K) = taps x input channels, walked in steps of 32 channels of one tap
 //
-// A 256-thread workgroup (4 waves) owns a BM x BN output tile. Each K-step stages a BM x 32 tile
-// of (shifted, zero-padded) activations and a BN x 32 tile of weights through LDS: global loads
-// for step s+1 are issued into registers before the MFMAs of step s and written to the other LDS
-// buffer after them, so one barrier per step suffices. Rows of both tiles are padded to 36 floats,
+// Work decomposition. Rows are handled in groups of 32 (one MFMA tile). The host gives every
+// workgroup a contiguous run of `gpb` row groups of one column tile, sized so that the grid is one
+// resident round of the chip (256 CUs x 2 workgroups); the workgroup walks its run in tiles of up to
+// 4 groups (128 rows) and the last, shorter tile only issues the MFMAs of the groups it has. This
+// removes the "3.06 rounds cost 4" quantisation of a fixed 128-row tiling.
+//
+// Per tile, each K-step stages a (<=128) x 32 tile of shifted, zero-padded activations and a
+// BN x 32 tile of weights through LDS: buffer loads for step s+1 are issued into registers before
+// the MFMAs of step s and written to the other LDS buffer after them, so one barrier per step
+// suffices. All loads are branch-free: an out-of-image tap, a row or column past the end, or a
+// channel past Cin gets the offset 0x80000000, which the buffer descriptor's range check turns into
+// zeros. Per-row offsets are recomputed only when the tap changes. LDS rows are padded to 36 floats,
 // which makes the 16-byte fragment reads (lane = row) conflict-free.
 //
 // Fragment mapping: lane l = (r = l & 31, h = l >> 5) reads four consecutive k at 4h..4h+3 of an
 // 8-wide chunk; MFMA number e of the chunk multiplies element e of the A and B fragments, i.e.
 // k = e (lanes h=0) and k = 4+e (lanes h=1). A and B use the same permutation, so the sum over
 // the chunk is complete after four MFMAs. Accumulator: column = lane & 31,
-// row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+// row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5). The 4 waves form a 2 x 2 grid; row group g of a
+// tile belongs to wave row g & 1 (slot g >> 1), so a short tile keeps both wave rows busy.
+#include <type_traits>
+
 #include "common.h"
 
 using ddpm::as_stream;
@@ -23,14 +34,18 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MODE_CONV3 = 0;  // 3x3, pad 1
-constexpr int MODE_CONV1 = 1;  // 1x1
-constexpr int MODE_CONVT = 2;  // 2x2 stride-2 transposed: GEMM + scatter
+constexpr int MODE_CONV3 = 0;        // 3x3, pad 1
+constexpr int MODE_CONV1 = 1;        // 1x1
+constexpr int MODE_CONVT = 2;        // 2x2 stride-2 transposed: GEMM + scatter
 constexpr int MODE_CONVT_DGRAD = 3;  // data gradient of MODE_CONVT: 4 taps gathered from the (out_h x out_w) image
 
 constexpr int BK = 32;
-constexpr int LDS_LD = 36;  // padded row length in floats
+constexpr int LDS_LD = 36;             // padded row length in floats
+constexpr int BM = 128;                // rows of a full tile (4 groups)
+constexpr unsigned OOB = 0x80000000u;  // any offset >= the descriptor's num_records reads as zero
+constexpr int kSlots = 512;            // resident workgroups: 256 CUs x 2 (LDS-limited)
 
 struct GemmParams {
     const float* src1;
@@ -48,7 +63,9 @@ struct GemmParams {
     int ldo, ldr, act;
     int out_h, out_w, off_y, off_x;
     int m_total, kc, taps;
-    int m_tiles, n_tiles;
+    int n_tiles, groups_total, gpb;
+    long long src1_pixels, src2_pixels;  // pixels (rows of ld floats) in each source tensor
+    unsigned w_bytes;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -57,184 +74,254 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long long bytes) {
+    const unsigned n = bytes > 0x7fffffffll ? 0x7fffffffu : static_cast<unsigned>(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n, 0x00020000);
+}
+
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+template <int BN, int MODE, bool DUAL>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
-    constexpr int TM = BM / (WM * 32);
-    constexpr int TN = BN / (WN * 32);
-    constexpr int AR = BM / 32;  // A rows loaded per thread
-    constexpr int BR = BN / 32;  // B rows loaded per thread
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int TN = BN / 64;  // 32-column MFMA tiles per wave (2 x 2 waves)
+    constexpr int BR = BN / 32;  // weight rows loaded per thread
 
     __shared__ __attribute__((aligned(16))) float smem[2][(BM + BN) * LDS_LD];
     __shared__ int4 rowinfo[BM];  // (pixel index or -1, b, y, x) of every tile row
 
-    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a
-    // contiguous run of tiles (neighbouring tiles share activation rows in that XCD's L2).
-    const int nwg = p.m_tiles * p.n_tiles;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a
+    // contiguous run of row ranges (neighbouring ranges share activation rows in that XCD's L2).
+    const int nwg = gridDim.x;
     int id = blockIdx.x;
     {
-        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        const int q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
+        id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
     }
     const int n_tile = id % p.n_tiles;
-    const int m_tile = id / p.n_tiles;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int m_block = id / p.n_tiles;
+    const int n0 = n_tile * BN;
+    const int g_begin = m_block * p.gpb;
+    const int g_end = min(p.groups_total, g_begin + p.gpb);
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform for the compiler
+    const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int lrow = tid >> 3, lc4 = tid & 7;
 
-    if (tid < BM) {
-        const int m = m0 + tid;
-        int4 info = make_int4(-1, 0, 0, 0);
-        if (m < p.m_total) {
-            const int per = p.win_h * p.win_w;
-            const int b = m / per;
-            const int rem = m - b * per;
-            const int wy = rem / p.win_w;
-            const int y = p.win_y0 + wy, x = p.win_x0 + (rem - wy * p.win_w);
-            info = make_int4((b * p.in_h + y) * p.in_w + x, b, y, x);
-        }
-        rowinfo[tid] = info;
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+    // weight rows of this thread: byte offset of (tap 0, row n, channel 0), or OOB past the last column
+    unsigned wrow[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        wrow[i] = n < p.n_total ? static_cast<unsigned>(n) * p.ctot * 4u : OOB;
     }
-    __syncthreads();
-
-    int4 ri[AR];
-#pragma unroll
-    for (int i = 0; i < AR; ++i) ri[i] = rowinfo[lrow + 32 * i];
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    f32x4 areg[AR], breg[BR];
+    const unsigned tap_stride_w = static_cast<unsigned>(p.n_total) * p.ctot * 4u;
     const int steps = p.taps * p.kc;
 
-    auto load_global = [&](int tap, int kc) {
-        int dy = 0, dx = 0;
-        if (MODE == MODE_CONV3) {
-            dy = tap / 3 - 1;
-            dx = tap - (tap / 3) * 3 - 1;
-        }
-        const int c = kc * BK + lc4 * 4;
-        const bool c_ok = c < p.ctot;
-        const bool first = c < p.c1;
-        const float* base = first ? p.src1 : p.src2;
-        const int ld = first ? p.ld1 : p.ld2;
-        const int cc = first ? c : c - p.c1;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (MODE == MODE_CONVT_DGRAD) {
-                // tap = a*2 + b: the output pixel (2y+a+off_y, 2x+b+off_x) this input pixel fed
-                const int oy = 2 * ri[i].z + (tap >> 1) + p.off_y, ox = 2 * ri[i].w + (tap & 1) + p.off_x;
-                if (c_ok && ri[i].x >= 0 && oy >= 0 && oy < p.out_h && ox >= 0 && ox < p.out_w) {
-                    const int64_t pix = (static_cast<int64_t>(ri[i].y) * p.out_h + oy) * p.out_w + ox;
-                    v = *reinterpret_cast<const f32x4*>(base + pix * ld + cc);
-                }
-            } else {
-                const int yy = ri[i].z + dy, xx = ri[i].w + dx;
-                const bool ok = c_ok && ri[i].x >= 0 && yy >= 0 && yy < p.in_h && xx >= 0 && xx < p.in_w;
-                if (ok) {
-                    const int64_t pix = static_cast<int64_t>(ri[i].x) + dy * p.in_w + dx;
-                    v = *reinterpret_cast<const f32x4*>(base + pix * ld + cc);
-                }
-            }
-            areg[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const int n = n0 + lrow + 32 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (c_ok && n < p.n_total)
-                v = *reinterpret_cast<const f32x4*>(p.w + (static_cast<int64_t>(tap) * p.n_total + n) * p.ctot + c);
-            breg[i] = v;
-        }
-    };
-    auto store_lds = [&](int buf) {
-        float* sA = smem[buf];
-        float* sB = smem[buf] + BM * LDS_LD;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(sA + (lrow + 32 * i) * LDS_LD + lc4 * 4) = areg[i];
-#pragma unroll
-        for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(sB + (lrow + 32 * i) * LDS_LD + lc4 * 4) = breg[i];
-    };
+    for (int g0 = g_begin; g0 < g_end; g0 += 4) {
+        const int kg = min(4, g_end - g0);  // row groups of this tile (workgroup-uniform)
+        const int m0 = g0 * 32;
 
-    int tap = 0, kc = 0;
-    load_global(0, 0);
-    store_lds(0);
-    __syncthreads();
-
-    for (int s = 0; s < steps; ++s) {
-        const int buf = s & 1;
-        const bool more = s + 1 < steps;
-        if (more) {
-            if (++kc == p.kc) {
-                kc = 0;
-                ++tap;
+        __syncthreads();  // the previous tile's epilogue still reads rowinfo
+        if (tid < BM) {
+            const int m = m0 + tid;
+            int4 info = make_int4(-1, 0, 0, 0);
+            if (tid < kg * 32 && m < p.m_total) {
+                const int per = p.win_h * p.win_w;
+                const int b = m / per;
+                const int rem = m - b * per;
+                const int wy = rem / p.win_w;
+                const int y = p.win_y0 + wy, x = p.win_x0 + (rem - wy * p.win_w);
+                info = make_int4((b * p.in_h + y) * p.in_w + x, b, y, x);
             }
-            load_global(tap, kc);
+            rowinfo[tid] = info;
         }
-        const float* sA = smem[buf] + (wm * TM * 32 + r) * LDS_LD + h * 4;
-        const float* sB = smem[buf] + BM * LDS_LD + (wn * TN * 32 + r) * LDS_LD + h * 4;
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LDS_LD + kk * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(sB + j * 32 * LDS_LD + kk * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-        }
-        if (more) store_lds(buf ^ 1);
         __syncthreads();
-    }
 
-    // ---- epilogue -------------------------------------------------------------------------
+        int4 ri[4];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + r;
-        if (n >= p.n_total) continue;
-        int co = n, qa = 0, qb = 0;
-        if (MODE == MODE_CONVT) {
-            const int q = n / p.cout;
-            co = n - q * p.cout;
-            qa = q >> 1;
-            qb = q & 1;
+        for (int i = 0; i < 4; ++i) ri[i] = rowinfo[lrow + 32 * i];
+
+        // Activation descriptors based just before this tile's first pixel, so that offsets stay
+        // small whatever the tensor size (transposed-conv gradient gathers: absolute offsets).
+        long long pix0 = 0;
+        if (MODE != MODE_CONVT_DGRAD) {
+            const int first = __builtin_amdgcn_readfirstlane(rowinfo[0].x);
+            pix0 = first - p.in_w - 1;
+            if (pix0 < 0) pix0 = 0;
         }
-        const float sc = p.scale ? p.scale[co] : 1.0f;
-        const float sh = p.shift ? p.shift[co] : 0.0f;
+        const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.src1 + pix0 * p.ld1, (p.src1_pixels - pix0) * p.ld1 * 4ll);
+        const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(p.src2 + pix0 * p.ld2, (p.src2_pixels - pix0) * p.ld2 * 4ll);
+        const int pix0i = static_cast<int>(pix0);
+
+        f32x16 acc[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int4 info = rowinfo[row];
-                if (info.x < 0) continue;
-                float v = acc[i][j][e] * sc + sh;
-                if (MODE == MODE_CONVT) {
-                    const int oy = 2 * info.z + qa + p.off_y, ox = 2 * info.w + qb + p.off_x;
-                    if (oy < 0 || oy >= p.out_h || ox < 0 || ox >= p.out_w) continue;
-                    const int64_t opix = (static_cast<int64_t>(info.y) * p.out_h + oy) * p.out_w + ox;
-                    p.out[opix * p.ldo + co] = v;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        unsigned aoff1[4], aoff2[4];  // per-row byte offset of channel 0 for the current tap, or OOB
+        auto set_tap = [&](int tap) {
+            int dy = 0, dx = 0;
+            if (MODE == MODE_CONV3) {
+                dy = tap / 3 - 1;
+                dx = tap - (tap / 3) * 3 - 1;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bool ok = ri[i].x >= 0;
+                int rel;
+                if (MODE == MODE_CONVT_DGRAD) {
+                    // tap = a*2 + b: the output pixel (2y+a+off_y, 2x+b+off_x) this input pixel fed
+                    const int oy = 2 * ri[i].z + (tap >> 1) + p.off_y, ox = 2 * ri[i].w + (tap & 1) + p.off_x;
+                    ok = ok && oy >= 0 && oy < p.out_h && ox >= 0 && ox < p.out_w;
+                    rel = (ri[i].y * p.out_h + oy) * p.out_w + ox;
                 } else {
-                    const int64_t pix = info.x;
-                    if (p.residual) v += p.residual[pix * p.ldr + n];
-                    v = apply_act(v, p.act);
-                    if (p.temb) v += p.temb[static_cast<int64_t>(info.y) * p.cout + n];
-                    p.out[pix * p.ldo + n] = v;
+                    const int yy = ri[i].z + dy, xx = ri[i].w + dx;
+                    ok = ok && yy >= 0 && yy < p.in_h && xx >= 0 && xx < p.in_w;
+                    rel = ri[i].x - pix0i + dy * p.in_w + dx;
+                }
+                aoff1[i] = ok ? static_cast<unsigned>(rel) * p.ld1 * 4u : OOB;
+                if (DUAL) aoff2[i] = ok ? static_cast<unsigned>(rel) * p.ld2 * 4u : OOB;
+            }
+        };
+
+        f32x4 areg[4], breg[BR];
+        auto load_global = [&](int tap, int kc) {
+            const int c = kc * BK + lc4 * 4;
+            const unsigned cb = c < p.ctot ? static_cast<unsigned>(c) * 4u : OOB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < kg) {
+                    if (DUAL) {
+                        // exactly one of the two loads is in range; the other returns zeros
+                        const unsigned o1 = c < p.c1 ? aoff1[i] + cb : OOB;
+                        const unsigned o2 = (c >= p.c1 && c < p.ctot) ? aoff2[i] + static_cast<unsigned>(c - p.c1) * 4u : OOB;
+                        const f32x4 v1 = buf_load(rs1, o1), v2 = buf_load(rs2, o2);
+                        areg[i] = v1 + v2;
+                    } else {
+                        areg[i] = buf_load(rs1, aoff1[i] + cb);
+                    }
+                }
+            }
+            const unsigned tb = static_cast<unsigned>(tap) * tap_stride_w;
+#pragma unroll
+            for (int i = 0; i < BR; ++i) breg[i] = buf_load(rs_w, wrow[i] + tb + cb);
+        };
+        auto store_lds = [&](int buf) {
+            float* sA = smem[buf];
+            float* sB = smem[buf] + BM * LDS_LD;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < kg) *reinterpret_cast<f32x4*>(sA + (lrow + 32 * i) * LDS_LD + lc4 * 4) = areg[i];
+#pragma unroll
+            for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(sB + (lrow + 32 * i) * LDS_LD + lc4 * 4) = breg[i];
+        };
+
+        int tap = 0, kc = 0;
+        set_tap(0);
+        load_global(0, 0);
+        store_lds(0);
+        __syncthreads();
+
+        // The K loop is instantiated per SLOTS = row groups this wave owns in the tile (groups wm and
+        // wm+2; 2 in a full tile), so that each variant keeps its accumulators in fixed registers.
+        const int my_slots = (kg - wm + 1) >> 1;
+        auto k_loop = [&](auto slots_tag) {
+            constexpr int SLOTS = decltype(slots_tag)::value;
+            for (int s = 0; s < steps; ++s) {
+                const int buf = s & 1;
+                const bool more = s + 1 < steps;
+                if (more) {
+                    if (++kc == p.kc) {
+                        kc = 0;
+                        ++tap;
+                        set_tap(tap);
+                    }
+                    load_global(tap, kc);
+                }
+                if (SLOTS > 0) {
+                    const float* sA = smem[buf] + (wm * 32 + r) * LDS_LD + h * 4;
+                    const float* sB = smem[buf] + BM * LDS_LD + (wn * TN * 32 + r) * LDS_LD + h * 4;
+                    constexpr int SL = SLOTS > 0 ? SLOTS : 1;
+                    f32x4 a[2][SL], b[2][TN];
+                    // fragments of chunk kk+1 are requested before the MFMAs of chunk kk
+                    auto fetch = [&](int kk, int which) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) b[which][j] = *reinterpret_cast<const f32x4*>(sB + j * 32 * LDS_LD + kk * 8);
+#pragma unroll
+                        for (int i = 0; i < SL; ++i) a[which][i] = *reinterpret_cast<const f32x4*>(sA + i * 64 * LDS_LD + kk * 8);
+                    };
+                    fetch(0, 0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int kk = 0; kk < BK / 8; ++kk) {
+                        const int cur = kk & 1;
+                        if (kk + 1 < BK / 8) fetch(kk + 1, cur ^ 1);
+                        // The next step's tile goes to the other LDS buffer (free since the last
+                        // barrier) while MFMAs are still queued, not in a bubble after them.
+                        if (kk == BK / 8 - 1 && more) store_lds(buf ^ 1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int i = 0; i < SL; ++i)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][e], b[cur][j][e], acc[i][j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                } else if (more) {
+                    store_lds(buf ^ 1);
+                }
+                __syncthreads();
+            }
+        };
+        if (my_slots == 2) k_loop(std::integral_constant<int, 2>{});
+        else if (my_slots == 1) k_loop(std::integral_constant<int, 1>{});
+        else k_loop(std::integral_constant<int, 0>{});
+
+        // ---- epilogue ---------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + r;
+            if (n >= p.n_total) continue;
+            int co = n, qa = 0, qb = 0;
+            if (MODE == MODE_CONVT) {
+                const int q = n / p.cout;
+                co = n - q * p.cout;
+                qa = q >> 1;
+                qb = q & 1;
+            }
+            const float sc = p.scale ? p.scale[co] : 1.0f;
+            const float sh = p.shift ? p.shift[co] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i >= my_slots) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (i * 2 + wm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int4 info = rowinfo[row];
+                    if (info.x < 0) continue;
+                    float v = acc[i][j][e] * sc + sh;
+                    if (MODE == MODE_CONVT) {
+                        const int oy = 2 * info.z + qa + p.off_y, ox = 2 * info.w + qb + p.off_x;
+                        if (oy < 0 || oy >= p.out_h || ox < 0 || ox >= p.out_w) continue;
+                        const int64_t opix = (static_cast<int64_t>(info.y) * p.out_h + oy) * p.out_w + ox;
+                        p.out[opix * p.ldo + co] = v;
+                    } else {
+                        const int64_t pix = info.x;
+                        if (p.residual) v += p.residual[pix * p.ldr + n];
+                        v = apply_act(v, p.act);
+                        if (p.temb) v += p.temb[static_cast<int64_t>(info.y) * p.cout + n];
+                        p.out[pix * p.ldo + n] = v;
+                    }
                 }
             }
         }
@@ -243,23 +330,40 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
 
 template <int MODE>
 int launch_gemm(GemmParams& p, hipStream_t s) {
-    // Tile choice: the narrowest BN that wastes the fewest padded columns (128 preferred), and the
-    // small 64x64 tile when 128-row tiles would leave most of the 256 CUs without a workgroup.
-    const int pad128 = (p.n_total + 127) / 128 * 128, pad64 = (p.n_total + 63) / 64 * 64;
-    int bm = 128, bn = pad128 <= pad64 ? 128 : 64;
-    const int64_t blocks = static_cast<int64_t>((p.m_total + bm - 1) / bm) * ((p.n_total + bn - 1) / bn);
-    if (blocks < 256) bm = bn = 64;
-    p.m_tiles = (p.m_total + bm - 1) / bm;
-    p.n_tiles = (p.n_total + bn - 1) / bn;
-    const int64_t grid = static_cast<int64_t>(p.m_tiles) * p.n_tiles;
+    // Column tile and run length: minimise (row groups per workgroup) x (columns per tile), the time
+    // of the busiest workgroup when the whole grid is one resident round. The 64-column tile stages
+    // as many activation bytes for half the MFMA work, and measures ~35 % slower per FLOP, hence the handicap.
+    p.groups_total = (p.m_total + 31) / 32;
+    const long long wb = 4ll * p.taps * p.n_total * p.ctot;
+    if (wb >= 0x7fffffffll) return ddpm::fail_invalid("weight tensor of 2 GiB or more");
+    p.w_bytes = static_cast<unsigned>(wb);
+    int best_bn = 0, best_gpb = 0;
+    double best_cost = 0.0;
+    for (int bn : {128, 64}) {
+        const int nt = (p.n_total + bn - 1) / bn;
+        int per_tile = kSlots / nt;
+        if (per_tile < 1) per_tile = 1;
+        const int gpb = (p.groups_total + per_tile - 1) / per_tile;
+        const double cost = static_cast<double>(gpb) * bn * (bn == 64 ? 1.35 : 1.0);
+        if (best_bn == 0 || cost < best_cost) {
+            best_bn = bn;
+            best_gpb = gpb;
+            best_cost = cost;
+        }
+    }
+    p.gpb = best_gpb;
+    p.n_tiles = (p.n_total + best_bn - 1) / best_bn;
+    const int64_t grid = static_cast<int64_t>((p.groups_total + p.gpb - 1) / p.gpb) * p.n_tiles;
     if (grid <= 0 || grid > 0x7fffffffll) return ddpm::fail_invalid("conv grid size");
     const dim3 g(static_cast<unsigned>(grid)), b(256);
-    if (bm == 128 && bn == 128)
-        conv_gemm_kernel<128, 128, 2, 2, MODE><<<g, b, 0, s>>>(p);
-    else if (bm == 128)
-        conv_gemm_kernel<128, 64, 2, 2, MODE><<<g, b, 0, s>>>(p);
-    else
-        conv_gemm_kernel<64, 64, 2, 2, MODE><<<g, b, 0, s>>>(p);
+    const bool dual = p.c2 > 0;
+    if (best_bn == 128) {
+        if (dual) conv_gemm_kernel<128, MODE, true><<<g, b, 0, s>>>(p);
+        else conv_gemm_kernel<128, MODE, false><<<g, b, 0, s>>>(p);
+    } else {
+        if (dual) conv_gemm_kernel<64, MODE, true><<<g, b, 0, s>>>(p);
+        else conv_gemm_kernel<64, MODE, false><<<g, b, 0, s>>>(p);
+    }
     return ddpm::check_launch("conv_gemm_kernel");
 }
 
@@ -312,6 +416,8 @@ void fill_common(GemmParams& p, const ddpm_conv_desc* d, const float* src1, cons
     p.off_x = 0;
     p.kc = (p.ctot + BK - 1) / BK;
     p.m_total = d->batch * d->in_h * d->in_w;
+    p.src1_pixels = static_cast<long long>(d->batch) * d->in_h * d->in_w;
+    p.src2_pixels = p.src1_pixels;
 }
 
 // ---- weight repacking ---------------------------------------------------------------------
@@ -451,5 +557,9 @@ extern "C" int ddpm_convT2x2_dgrad(const ddpm_conv_desc* d, const float* dy, con
     p.out_w = d->out_w;
     p.off_y = d->off_y;
     p.off_x = d->off_x;
+    // the gather addresses dy with absolute 32-bit byte offsets
+    p.src1_pixels = static_cast<long long>(d->batch) * d->out_h * d->out_w;
+    p.src2_pixels = p.src1_pixels;
+    DDPM_REQUIRE(p.src1_pixels * d->ld1 * 4ll < 0x7fffffffll);
     return launch_gemm<MODE_CONVT_DGRAD>(p, as_stream(stream));
 }

@@ -162,9 +162,12 @@ int launch_wgrad(WgradParams& p, hipStream_t s) {
     p.m_tiles = (p.m_total + bt - 1) / bt;
     p.n_tiles = (p.n_total + bt - 1) / bt;
     const int64_t tiles = static_cast<int64_t>(p.m_tiles) * p.n_tiles * p.taps;
-    // enough pixel splits for ~4 workgroups per CU, at least 8 K-steps (256 pixels) each
-    int64_t splits = (1024 + tiles - 1) / tiles;
-    const int64_t max_splits = (p.k_total + 255) / 256;
+    // Pixel splits: fill the chip with whole rounds of workgroups. The 128-wide tile fits 2
+    // workgroups per CU (64 KB of LDS each), the 64-wide one 4: aim at two rounds of the resident
+    // capacity and never exceed it by a few stragglers, which would cost a whole extra round.
+    const int64_t slots = 256 * (big ? 2 : 4);
+    int64_t splits = (2 * slots) / tiles;
+    const int64_t max_splits = (p.k_total + 255) / 256;      // at least 8 K-steps per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int64_t chunk = (p.k_total + splits - 1) / splits;

@@ -74,12 +74,15 @@ class UNetEngine(TrainMixin):
         self.prof = None       # when a list: (kernel label, flops, start event, end event) per MFMA launch
 
     def _gemm_label(self, kind, m, n):
-        """Name of the conv_gemm_kernel instance the library picks for an m x n problem."""
-        pad128, pad64 = _round_up(n, 128), _round_up(n, 64)
-        bm, bn = 128, (128 if pad128 <= pad64 else 64)
-        if _round_up(m, bm) // bm * (_round_up(n, bn) // bn) < 256:
-            bm = bn = 64
-        return f"conv_gemm<{bm}x{bn},{kind}>"
+        """Name of the conv_gemm_kernel instance the library picks for an m x n problem (mirrors its cost rule)."""
+        groups = (m + 31) // 32
+        best = None
+        for bn in (128, 64):
+            per_tile = max(1, 512 // ((n + bn - 1) // bn))
+            cost = ((groups + per_tile - 1) // per_tile) * bn * (1.35 if bn == 64 else 1.0)
+            if best is None or cost < best[0]:
+                best = (cost, bn)
+        return f"conv_gemm<{best[1]},{kind}>"
 
     def _launch(self, label, flops, name, *args):
         if self.prof is None:

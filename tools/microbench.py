@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks through the C ABI (no model around them), for profiling runs.
+
+    python tools/microbench.py conv3x3 B H W Cin Cout [iters]
+    python tools/microbench.py wgrad   B H W Cin Cout [iters]
+    python tools/microbench.py attn    B N C [iters]         (forward + backward)
+    python tools/microbench.py step    NELEMS [iters]        (reverse-step kernel, HBM-bound)
+Prints the average launch time from HIP events and the achieved TFLOP/s or GB/s.
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from diffusion_model_amd._lib import ConvDesc, Epilogue, call  # noqa: E402
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    kind = sys.argv[1]
+    a = [int(v) for v in sys.argv[2:]]
+    dev = "cuda"
+    if kind in ("conv3x3", "wgrad"):
+        B, H, W, ci, co = a[:5]
+        iters = a[5] if len(a) > 5 else 20
+        x = torch.randn(B, H, W, ci, device=dev)
+        w = torch.randn(co, ci, 3, 3, device=dev) * (9 * ci) ** -0.5
+        wp = torch.empty(w.numel(), device=dev)
+        call("ddpm_pack_conv3x3", P(w), co, ci, 0, P(wp), S())
+        y = torch.empty(B, H, W, co, device=dev)
+        flops = 2.0 * B * H * W * co * ci * 9
+        if kind == "conv3x3":
+            d = ConvDesc(batch=B, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=2, ldr=0, out_h=H, out_w=W)
+            sc, sh = torch.ones(co, device=dev), torch.zeros(co, device=dev)
+            ep = Epilogue(P(sc), P(sh), None, None)
+            t = timeit(lambda: call("ddpm_conv3x3_fwd", C.byref(d), P(x), None, P(wp), C.byref(ep), P(y), S()), iters)
+        else:
+            dy = torch.randn(B, H, W, co, device=dev)
+            packed, gw = torch.empty(w.numel(), device=dev), torch.empty_like(w)
+            t = timeit(lambda: call("ddpm_conv3x3_wgrad", P(dy), co, co, P(x), ci, ci, B, H, W, P(packed), P(gw), S()), iters)
+        print(f"{kind} B={B} {H}x{W} {ci}->{co}: {t*1e6:.1f} us  {flops/t/1e12:.1f} TFLOP/s")
+    elif kind == "attn":
+        B, N, c = a[:3]
+        iters = a[3] if len(a) > 3 else 10
+        dq = max(8, c // 8)
+        qkv = torch.randn(B, N, 2 * dq + c, device=dev) * 0.5
+        x, dy = torch.randn(B, N, c, device=dev), torch.randn(B, N, c, device=dev)
+        g = torch.full((1,), 0.5, device=dev)
+        out, raw, lse = torch.empty_like(x), torch.empty_like(x), torch.empty(B, N, device=dev)
+        t = timeit(lambda: call("ddpm_attention_fwd", P(qkv), P(x), c, P(g), P(out), c, P(raw), P(lse), None, B, N, c, dq, S()), iters)
+        print(f"attn fwd B={B} N={N} C={c}: {t*1e6:.1f} us  {2.0*B*N*N*(dq+c)/t/1e12:.1f} TFLOP/s")
+        ws, es = torch.empty(4096, dtype=torch.float64, device=dev), torch.empty(B, N, device=dev)
+        dqkv, dg = torch.empty_like(qkv), torch.empty(1, device=dev)
+        t = timeit(lambda: call("ddpm_attention_bwd", P(qkv), P(dy), c, P(raw), P(lse), P(g), P(ws), P(es), P(dqkv), P(dg), B, N, c, dq,
+                                S()), iters)
+        print(f"attn bwd B={B} N={N} C={c}: {t*1e6:.1f} us  {2.0*B*N*N*(3*dq+3*c)/t/1e12:.1f} TFLOP/s (algorithmic, no recompute)")
+    elif kind == "step":
+        n = a[0]
+        iters = a[1] if len(a) > 1 else 50
+        x, e, z, o = (torch.randn(n, device=dev) for _ in range(4))
+        t = timeit(lambda: call("ddpm_reverse_step", P(x), P(e), None, 0.0, P(z), 1.01, 0.02, 0.1, P(o), n, S()), iters)
+        print(f"reverse_step n={n}: {t*1e6:.1f} us  {16.0*n/t/1e9:.1f} GB/s")
+    else:
+        sys.exit(__doc__)
+
+
+if __name__ == "__main__":
+    main()
