@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libddpm_mi355x.so")
+LIB_PATH = os.environ.get("DDPM_LIB") or os.path.join(_HERE, "libddpm_mi355x.so")   # DDPM_LIB: diagnostic builds
 
 P, I32, I64, F32, F64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 

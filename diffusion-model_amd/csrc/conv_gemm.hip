@@ -46,6 +46,9 @@ constexpr int LDS_LD = 36;             // padded row length in floats
 constexpr int BM = 128;                // rows of a full tile (4 groups)
 constexpr unsigned OOB = 0x80000000u;  // any offset >= the descriptor's num_records reads as zero
 constexpr int kSlots = 512;            // resident workgroups: 256 CUs x 2 (LDS-limited)
+#ifndef DDPM_ABLATE
+#define DDPM_ABLATE 0                  // diagnostic builds only: 1 = no staging in the K loop, 2 = also no barrier, 3 = no MFMAs, 4 = loads but no LDS stores, 5 = LDS stores but no loads
+#endif
 
 struct GemmParams {
     const float* src1;
@@ -194,12 +197,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
         };
 
         f32x4 areg[4], breg[BR];
-        auto load_global = [&](int tap, int kc) {
+        // full = the tile has all 4 row groups (no per-group guards: straight-line code)
+        auto load_a = [&](int kc, bool full) {
             const int c = kc * BK + lc4 * 4;
             const unsigned cb = c < p.ctot ? static_cast<unsigned>(c) * 4u : OOB;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (i < kg) {
+                if (full || i < kg) {
                     if (DUAL) {
                         // exactly one of the two loads is in range; the other returns zeros
                         const unsigned o1 = c < p.c1 ? aoff1[i] + cb : OOB;
@@ -211,31 +215,40 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
                     }
                 }
             }
+        };
+        auto load_b = [&](int tap, int kc) {
+            const int c = kc * BK + lc4 * 4;
+            const unsigned cb = c < p.ctot ? static_cast<unsigned>(c) * 4u : OOB;
             const unsigned tb = static_cast<unsigned>(tap) * tap_stride_w;
 #pragma unroll
             for (int i = 0; i < BR; ++i) breg[i] = buf_load(rs_w, wrow[i] + tb + cb);
         };
-        auto store_lds = [&](int buf) {
+        auto store_lds = [&](int buf, bool full) {
             float* sA = smem[buf];
             float* sB = smem[buf] + BM * LDS_LD;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (i < kg) *reinterpret_cast<f32x4*>(sA + (lrow + 32 * i) * LDS_LD + lc4 * 4) = areg[i];
+                if (full || i < kg) *reinterpret_cast<f32x4*>(sA + (lrow + 32 * i) * LDS_LD + lc4 * 4) = areg[i];
 #pragma unroll
             for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(sB + (lrow + 32 * i) * LDS_LD + lc4 * 4) = breg[i];
         };
 
         int tap = 0, kc = 0;
         set_tap(0);
-        load_global(0, 0);
-        store_lds(0);
+        load_a(0, false);
+        load_b(0, 0);
+        store_lds(0, false);
         __syncthreads();
 
         // The K loop is instantiated per SLOTS = row groups this wave owns in the tile (groups wm and
         // wm+2; 2 in a full tile), so that each variant keeps its accumulators in fixed registers.
+        // Inside a step the staging of the next step is spread between the MFMA chunks (loads after
+        // the first two chunks' fragments are requested, LDS stores before the last chunk), so that a
+        // wave's own matrix work covers its staging instead of leaving a bubble before it.
         const int my_slots = (kg - wm + 1) >> 1;
-        auto k_loop = [&](auto slots_tag) {
+        auto k_loop = [&](auto slots_tag, auto full_tag) {
             constexpr int SLOTS = decltype(slots_tag)::value;
+            constexpr bool FULL = decltype(full_tag)::value;
             for (int s = 0; s < steps; ++s) {
                 const int buf = s & 1;
                 const bool more = s + 1 < steps;
@@ -245,14 +258,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
                         ++tap;
                         set_tap(tap);
                     }
-                    load_global(tap, kc);
                 }
-                if (SLOTS > 0) {
+                if (SLOTS > 0 && DDPM_ABLATE != 3) {
                     const float* sA = smem[buf] + (wm * 32 + r) * LDS_LD + h * 4;
                     const float* sB = smem[buf] + BM * LDS_LD + (wn * TN * 32 + r) * LDS_LD + h * 4;
                     constexpr int SL = SLOTS > 0 ? SLOTS : 1;
                     f32x4 a[2][SL], b[2][TN];
-                    // fragments of chunk kk+1 are requested before the MFMAs of chunk kk
                     auto fetch = [&](int kk, int which) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) b[which][j] = *reinterpret_cast<const f32x4*>(sB + j * 32 * LDS_LD + kk * 8);
@@ -260,14 +271,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
                         for (int i = 0; i < SL; ++i) a[which][i] = *reinterpret_cast<const f32x4*>(sA + i * 64 * LDS_LD + kk * 8);
                     };
                     fetch(0, 0);
-                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int kk = 0; kk < BK / 8; ++kk) {
                         const int cur = kk & 1;
                         if (kk + 1 < BK / 8) fetch(kk + 1, cur ^ 1);
-                        // The next step's tile goes to the other LDS buffer (free since the last
-                        // barrier) while MFMAs are still queued, not in a bubble after them.
-                        if (kk == BK / 8 - 1 && more) store_lds(buf ^ 1);
+                        if (more && DDPM_ABLATE != 1 && DDPM_ABLATE != 2) {
+                            if (kk == 0 && DDPM_ABLATE != 5) load_a(kc, FULL);
+                            if (kk == 1 && DDPM_ABLATE != 5) load_b(tap, kc);
+                            if (kk == BK / 8 - 1 && DDPM_ABLATE != 4) store_lds(buf ^ 1, FULL);
+                            if (kk == BK / 8 - 1 && DDPM_ABLATE == 4) {   // keep the loads alive without storing them
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(areg[i]));
+#pragma unroll
+                                for (int i = 0; i < BR; ++i) asm volatile("" ::"v"(breg[i]));
+                            }
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -276,16 +294,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
                                 for (int j = 0; j < TN; ++j)
                                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][e], b[cur][j][e], acc[i][j], 0, 0, 0);
                     }
-                    __builtin_amdgcn_s_setprio(0);
                 } else if (more) {
-                    store_lds(buf ^ 1);
+                    load_a(kc, FULL);
+                    load_b(tap, kc);
+                    store_lds(buf ^ 1, FULL);
                 }
-                __syncthreads();
+                if (DDPM_ABLATE != 2) __syncthreads();
             }
         };
-        if (my_slots == 2) k_loop(std::integral_constant<int, 2>{});
-        else if (my_slots == 1) k_loop(std::integral_constant<int, 1>{});
-        else k_loop(std::integral_constant<int, 0>{});
+        using T0 = std::integral_constant<int, 0>;
+        using T1 = std::integral_constant<int, 1>;
+        using T2 = std::integral_constant<int, 2>;
+        if (kg == 4) {
+            if (my_slots == 2) k_loop(T2{}, std::true_type{});     // always, for a full tile
+            else k_loop(T1{}, std::true_type{});
+        } else if (my_slots == 2) k_loop(T2{}, std::false_type{});
+        else if (my_slots == 1) k_loop(T1{}, std::false_type{});
+        else k_loop(T0{}, std::false_type{});
 
         // ---- epilogue ---------------------------------------------------------------------
 #pragma unroll
