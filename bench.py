@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--workload", default="train", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,15 +107,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
         sys.exit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`")
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import diffusion_model_amd as pkg
+    from diffusion_model_amd import parallel
     from diffusion_model_amd._lib import call
     from diffusion_model_amd.schedule import step_coefficients_host
     wl = WORKLOADS[args.workload]
@@ -160,14 +168,7 @@ def main():
             opt.zero_grad()
             loss.backward()
             if dist is not None:                                             # data-parallel: average gradients over ranks
-                gs = [p.grad for p in params if p.grad is not None]
-                flat = torch.cat([g.reshape(-1) for g in gs])
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                flat.div_(world)
-                off = 0
-                for g in gs:
-                    g.copy_(flat[off:off + g.numel()].view_as(g))
-                    off += g.numel()
+                parallel.average_gradients(params)
             opt.step()
             state["loss"] = loss.item()
 

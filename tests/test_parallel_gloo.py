@@ -1,0 +1,75 @@
+"""world_size-2 checks of the multi-GPU helpers on CPU (gloo): batch sharding, gradient averaging,
+parameter broadcast, sharded sampling == single-process sampling."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from diffusion_model_amd import parallel
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 64, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+class ToyDiffusion:
+    """Deterministic stand-in with the reference's sample() contract (list of (cpu tensor, t))."""
+
+    def sample(self, x_shape, device="cpu", noise=None):
+        x = noise[0].clone()
+        stages = []
+        for i, z in enumerate(noise[1]):
+            x = 0.9 * x + 0.1 * z + 0.01 * x.mean(dim=(1, 2, 3), keepdim=True)      # per-sample only
+            stages.append((x.clone(), len(noise[1]) - 1 - i))
+        return stages
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # gradient averaging
+        torch.manual_seed(0)
+        lin = torch.nn.Linear(5, 3)
+        parallel.broadcast_parameters(lin)
+        w0 = lin.weight.detach().clone()
+        x = torch.full((4, 5), float(rank + 1))
+        lin(x).sum().backward()
+        local = [p.grad.clone() for p in lin.parameters()]
+        parallel.average_gradients(list(lin.parameters()))
+        mean_scale = sum(r + 1 for r in range(world)) / world
+        assert torch.allclose(lin.weight.grad, local[0] / (rank + 1) * mean_scale)
+        assert torch.allclose(lin.bias.grad, local[1])                 # identical on all ranks
+        assert torch.equal(lin.weight.detach(), w0)
+        # sharded sampling
+        g = torch.Generator().manual_seed(1)
+        shape = (5, 1, 4, 4)                                           # odd batch: uneven shards
+        noise = (torch.randn(shape, generator=g), [torch.randn(shape, generator=g) for _ in range(3)])
+        whole = ToyDiffusion().sample(shape, noise=noise)
+        got = parallel.sample_sharded(ToyDiffusion(), shape, "cpu", noise=noise)
+        assert [t for _, t in got] == [t for _, t in whole]
+        for (a, _), (b, _) in zip(got, whole):
+            assert torch.equal(a, b)
+        mine = parallel.sample_sharded(ToyDiffusion(), shape, "cpu", gather=False, noise=noise)
+        lo, hi = parallel.shard_range(5, world, rank)
+        assert torch.equal(mine[-1][0], whole[-1][0][lo:hi])
+        open(os.path.join(tmp, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_two_gloo(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
