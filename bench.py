@@ -90,6 +90,17 @@ def cpu_baseline(workload, wl, seconds=12.0):
                 sample=f"{n} training steps of the CPU oracle (torch-CPU autograd + Adam) at batch {B}")
 
 
+def log(msg, trace=False):
+    """Progress on stderr (stdout carries exactly one JSON line). trace messages (every rank) only
+    when DDPM_BENCH_TRACE=<seconds> is set, which also arms a stack dump after that many seconds."""
+    if trace:
+        if not os.environ.get("DDPM_BENCH_TRACE"):
+            return
+    elif int(os.environ.get("RANK", "0")) != 0:
+        return
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,14 +123,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-
+    log(f"world={world} device={dev} workload={args.workload}")
+    if os.environ.get("DDPM_BENCH_TRACE"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DDPM_BENCH_TRACE"]), exit=True)
     import diffusion_model_amd as pkg
     from diffusion_model_amd import parallel
     from diffusion_model_amd._lib import call
@@ -175,20 +182,49 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
+            log(f"rank {rank}: entering barrier", True)
             dist.barrier()
             torch.cuda.synchronize()
+            log(f"rank {rank}: left barrier", True)
 
+    prof = None
+    if world > 1:
+        # Per-kernel HIP events are taken in a pre-pass BEFORE the process group exists (2 steps, no
+        # collective), so that event recording never interleaves with RCCL traffic in the timed region.
+        log("multi-GPU: profiling pre-pass (no collectives)")
+        one_step()
+        model._engine.prof = []
+        one_step()
+        one_step()
+        torch.cuda.synchronize()
+        prof, prof_dt = model._engine.prof, None
+        model._engine.prof = None
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist_mod.init_process_group(args.backend, rank=rank, world_size=world)
+        dist = dist_mod
+        parallel.broadcast_parameters(model)
+
+    log("model built; warm-up")
     for _ in range(args.warmup):
         one_step()
-    model._engine.prof = []
+    log("timed steps")
+    if world == 1:
+        model._engine.prof = []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         one_step()
+        log(f"rank {rank}: step {i} issued", True)
     barrier()
     dt = time.perf_counter() - t0
-    prof = model._engine.prof
-    model._engine.prof = None
+    log(f"done: {dt / args.steps * 1e3:.2f} ms/step on this rank")
+    if world == 1:
+        prof = model._engine.prof
+        model._engine.prof = None
     if args.workload == "sample":
         assert torch.isfinite(state["x"]).all()
     else:
@@ -210,8 +246,9 @@ def main():
         a[2] += 1
     dom = max(agg.items(), key=lambda kv: kv[1][1])
     achieved = dom[1][0] / dom[1][1] / 1e12
+    prof_steps = args.steps if world == 1 else 2
     kernels = {k: dict(launches=v[2], avg_ms=round(v[1] / v[2] * 1e3, 4), tflops=round(v[0] / v[1] / 1e12, 2),
-                       share_of_step=round(v[1] / dt, 3)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+                       share_of_step=round(v[1] / prof_steps / sec_per_step, 3)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
     cfg = {"workload": wl["name"], "per_gpu_batch": B, "global_batch": total_b}
     if args.workload == "sample":
         cfg.update(T=T_FULL, step="one denoising step (UNet eval forward + noise draw + fused reverse-step kernel); "
@@ -227,7 +264,9 @@ def main():
         "config": cfg,
         "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                     "avg_launch_ms": round(dom[1][1] / dom[1][2] * 1e3, 4), "launches": dom[1][2]},
+                     "avg_launch_ms": round(dom[1][1] / dom[1][2] * 1e3, 4), "launches": dom[1][2],
+                     "measured": "HIP events around every launch of the timed steps" if world == 1 else
+                                 "HIP events in a 2-step pre-pass before the process group is created"},
         "kernels": kernels,
     }
     if rank == 0:
