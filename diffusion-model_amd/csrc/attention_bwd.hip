@@ -350,6 +350,299 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdParams p) {
         }
 }
 
+// ---- fast paths for the heavy layers (C = 64 or 128 channels, d_qk = C/8) ------------------------
+// Same mathematics as the generic kernels above, but the operand that is fixed for a wave's lifetime
+// (its 32 V rows in dkv, its 32 dO rows in dq) lives in registers, and the tiles that stream past
+// (Q/dO/lse/D, resp. K/V) are double-buffered in LDS with the next tile's global loads issued before
+// the MFMAs of the current one, so one barrier per tile suffices and no load sits on the critical path.
+template <int DQ, int CT, int WPS>   // WPS = waves per SIMD the register budget is sized for
+__global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_fast_kernel(const BwdParams p) {
+    constexpr int NCT = CT / 32;
+    constexpr int QLD = DQ + 4, DLD = CT + 4;
+    constexpr int DOPT = TQ * CT / 4 / 256;   // dO float4 per thread
+    constexpr int QF4 = TQ * DQ / 4;          // Q float4 per tile (<= 256)
+    __shared__ __attribute__((aligned(16))) float sQ[2][TQ * QLD];
+    __shared__ __attribute__((aligned(16))) float sDO[2][TQ * DLD];
+    __shared__ float sL[2][TQ], sD[2][TQ];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int j0 = (blockIdx.x * 4 + wave) * 32;
+    const bool wave_active = j0 < p.n;
+    const int kj = j0 + r;
+    const float g = p.gamma[0];
+    const float* base = p.qkv + static_cast<int64_t>(b) * p.n * p.lq;
+    const float* dyb = p.dy + static_cast<int64_t>(b) * p.n * p.ldd;
+    const float* lseb = p.lse + static_cast<int64_t>(b) * p.n;
+    const float* eb = p.e + static_cast<int64_t>(b) * p.n;
+
+    f32x4 kf[DQ / 8], vf[CT / 8];
+#pragma unroll
+    for (int kk = 0; kk < DQ / 8; ++kk) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kj < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(kj) * p.lq + DQ + kk * 8 + h * 4);
+        kf[kk] = v;
+    }
+#pragma unroll
+    for (int kk = 0; kk < CT / 8; ++kk) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kj < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(kj) * p.lq + 2 * DQ + kk * 8 + h * 4);
+        vf[kk] = v;
+    }
+
+    f32x16 dv[NCT], dk;
+#pragma unroll
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dv[t][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dk[e] = 0.f;
+
+    f32x4 doreg[DOPT], qreg;
+    float lreg = 0.f, dreg = 0.f;
+    auto load_tile = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < DOPT; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (CT / 4), c4 = f % (CT / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i0 + row < p.n) v = *reinterpret_cast<const f32x4*>(dyb + static_cast<int64_t>(i0 + row) * p.ldd + c4 * 4);
+            doreg[i] = v * g;
+        }
+        if (tid < QF4) {
+            const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i0 + row < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(i0 + row) * p.lq + c4 * 4);
+            qreg = v;
+        }
+        if (tid < TQ) {
+            const bool ok = i0 + tid < p.n;
+            lreg = ok ? lseb[i0 + tid] : 0.f;
+            dreg = ok ? g * eb[i0 + tid] : 0.f;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < DOPT; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (CT / 4), c4 = f % (CT / 4);
+            *reinterpret_cast<f32x4*>(&sDO[buf][row * DLD + c4 * 4]) = doreg[i];
+        }
+        if (tid < QF4) {
+            const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
+            *reinterpret_cast<f32x4*>(&sQ[buf][row * QLD + c4 * 4]) = qreg;
+        }
+        if (tid < TQ) {
+            sL[buf][tid] = lreg;
+            sD[buf][tid] = dreg;
+        }
+    };
+
+    const int qtiles = (p.n + TQ - 1) / TQ;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < qtiles; ++t) {
+        const int buf = t & 1, i0 = t * TQ;
+        const bool more = t + 1 < qtiles;
+        if (more) load_tile(i0 + TQ);
+        if (wave_active) {
+            const float* q = sQ[buf];
+            const float* dO = sDO[buf];
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < DQ / 8; ++kk) {
+                const f32x4 qf = *reinterpret_cast<const f32x4*>(q + r * QLD + kk * 8 + h * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[e], kf[kk][e], s, 0, 0, 0);
+            }
+#pragma unroll
+            for (int kk = 0; kk < CT / 8; ++kk) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(dO + r * DLD + kk * 8 + h * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], vf[kk][e], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int il = rowmap(e, h);
+                const bool ok = (i0 + il < p.n) && (kj < p.n);
+                const float pe = ok ? expf(s[e] - sL[buf][il]) : 0.f;
+                s[e] = pe;
+                dp[e] = pe * (dp[e] - sD[buf][il]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    dv[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(dO[rowmap(e, h) * DLD + ct * 32 + r], s[e], dv[ct], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float a = r < DQ ? q[rowmap(e, h) * QLD + r] : 0.f;
+                dk = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dp[e], dk, 0, 0, 0);
+            }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (!wave_active || kj >= p.n) return;
+    float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + kj) * p.lq;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int ch = ct * 32 + gq * 8 + h * 4;
+            f32x4 v = {dv[ct][gq * 4], dv[ct][gq * 4 + 1], dv[ct][gq * 4 + 2], dv[ct][gq * 4 + 3]};
+            *reinterpret_cast<f32x4*>(drow + 2 * DQ + ch) = v;
+        }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int d = gq * 8 + h * 4;
+        if (d >= DQ) continue;
+        f32x4 v = {dk[gq * 4], dk[gq * 4 + 1], dk[gq * 4 + 2], dk[gq * 4 + 3]};
+        *reinterpret_cast<f32x4*>(drow + DQ + d) = v;
+    }
+}
+
+template <int DQ, int CT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_fast_kernel(const BwdParams p) {
+    constexpr int KLD = DQ + 4, VLD = CT + 4;
+    constexpr int VPT = 32 * CT / 4 / 256;
+    constexpr int KF4 = 32 * DQ / 4;
+    __shared__ __attribute__((aligned(16))) float sK[2][32 * KLD];
+    __shared__ __attribute__((aligned(16))) float sV[2][32 * VLD];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int i0 = (blockIdx.x * 4 + wave) * 32;
+    const bool wave_active = i0 < p.n;
+    const int qi = i0 + r;
+    const bool q_ok = qi < p.n;
+    const float g = p.gamma[0];
+    const float* base = p.qkv + static_cast<int64_t>(b) * p.n * p.lq;
+
+    f32x4 qf[DQ / 8], dof[CT / 8];
+#pragma unroll
+    for (int kk = 0; kk < DQ / 8; ++kk) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q_ok) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(qi) * p.lq + kk * 8 + h * 4);
+        qf[kk] = v;
+    }
+#pragma unroll
+    for (int kk = 0; kk < CT / 8; ++kk) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q_ok) v = *reinterpret_cast<const f32x4*>(p.dy + (static_cast<int64_t>(b) * p.n + qi) * p.ldd + kk * 8 + h * 4);
+        dof[kk] = v * g;
+    }
+    const float lse_i = q_ok ? p.lse[static_cast<int64_t>(b) * p.n + qi] : 0.f;
+    const float d_i = q_ok ? g * p.e[static_cast<int64_t>(b) * p.n + qi] : 0.f;
+
+    f32x16 dq;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+
+    f32x4 kreg, vreg[VPT];
+    auto load_tile = [&](int j0) {
+        if (tid < KF4) {
+            const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + row < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(j0 + row) * p.lq + DQ + c4 * 4);
+            kreg = v;
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (CT / 4), c4 = f % (CT / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + row < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(j0 + row) * p.lq + 2 * DQ + c4 * 4);
+            vreg[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        if (tid < KF4) {
+            const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
+            *reinterpret_cast<f32x4*>(&sK[buf][row * KLD + c4 * 4]) = kreg;
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (CT / 4), c4 = f % (CT / 4);
+            *reinterpret_cast<f32x4*>(&sV[buf][row * VLD + c4 * 4]) = vreg[i];
+        }
+    };
+
+    const int ktiles = (p.n + 31) / 32;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ktiles; ++t) {
+        const int buf = t & 1, j0 = t * 32;
+        const bool more = t + 1 < ktiles;
+        if (more) load_tile(j0 + 32);
+        if (wave_active) {
+            const float* k = sK[buf];
+            const float* v = sV[buf];
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < DQ / 8; ++kk) {
+                const f32x4 kfr = *reinterpret_cast<const f32x4*>(k + r * KLD + kk * 8 + h * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kfr[e], qf[kk][e], s, 0, 0, 0);
+            }
+#pragma unroll
+            for (int kk = 0; kk < CT / 8; ++kk) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(v + r * VLD + kk * 8 + h * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], dof[kk][e], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool ok = q_ok && (j0 + rowmap(e, h) < p.n);
+                const float pe = ok ? expf(s[e] - lse_i) : 0.f;
+                dp[e] = pe * (dp[e] - d_i);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float a = r < DQ ? k[rowmap(e, h) * KLD + r] : 0.f;
+                dq = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dp[e], dq, 0, 0, 0);
+            }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    if (!wave_active || !q_ok) return;
+    float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + qi) * p.lq;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int d = gq * 8 + h * 4;
+        if (d >= DQ) continue;
+        f32x4 v = {dq[gq * 4], dq[gq * 4 + 1], dq[gq * 4 + 2], dq[gq * 4 + 3]};
+        *reinterpret_cast<f32x4*>(drow + d) = v;
+    }
+}
+
+template <int DQ, int CT>
+int launch_bwd_fast(const BwdParams& p, int batch, hipStream_t s) {
+    const dim3 grid((p.n + 127) / 128, 1, batch);
+#ifndef DDPM_DKV_WPS
+#define DDPM_DKV_WPS 1
+#endif
+    // 128 channels: V rows (64 registers) + dV accumulators (64) + scores do not fit 256 registers
+    // without spilling into the tile loop, so that variant is sized for one wave per SIMD.
+    if (CT > 64) attn_bwd_dkv_fast_kernel<DQ, CT, DDPM_DKV_WPS><<<grid, 256, 0, s>>>(p);
+    else attn_bwd_dkv_fast_kernel<DQ, CT, 2><<<grid, 256, 0, s>>>(p);
+    attn_bwd_dq_fast_kernel<DQ, CT><<<grid, 256, 0, s>>>(p);
+    return ddpm::check_launch("attn_bwd_fast");
+}
+
 template <int DQ>
 int launch_bwd(const BwdParams& p, int batch, hipStream_t s) {
     const int blocks_n = (p.n + 127) / 128;
@@ -401,6 +694,8 @@ extern "C" int ddpm_attention_bwd(const float* qkv, const float* dy, int ldd, co
     p.dqp = dq;
     p.lq = 2 * dq + c;
     p.ldd = ldd;
+    if (c == 64 && dq == 8) return launch_bwd_fast<8, 64>(p, batch, s);
+    if (c == 128 && dq == 16) return launch_bwd_fast<16, 128>(p, batch, s);
     switch (dq) {
         case 8: return launch_bwd<8>(p, batch, s);
         case 16: return launch_bwd<16>(p, batch, s);
