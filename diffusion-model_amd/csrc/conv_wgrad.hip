@@ -38,11 +38,22 @@ struct WgradParams {
     int m_tiles, n_tiles;
 };
 
+constexpr unsigned OOB = 0x80000000u;  // offsets at or beyond the buffer descriptor's range read as zero
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long long bytes) {
+    const unsigned n = bytes > 0x7fffffffll ? 0x7fffffffu : (bytes < 0 ? 0u : static_cast<unsigned>(bytes));
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
 template <int BT, int MODE>  // BT x BT output tile (channels x channels)
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int TT = BT / 64;           // 32x32 MFMA tiles per wave per dimension
     constexpr int F4R = BT / 4;           // float4 per tile row
     constexpr int LPT = BKP * F4R / 256;  // float4 loads per thread per operand
+    constexpr int RSTEP = 256 / F4R;      // rows between a thread's consecutive loads
     __shared__ __attribute__((aligned(16))) float sA[2][BKP * BT];
     __shared__ __attribute__((aligned(16))) float sB[2][BKP * BT];
 
@@ -55,7 +66,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int k_begin = split * p.k_chunk;
     const int k_end = min(p.k_total, k_begin + p.k_chunk);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     int dy = 0, dx = 0;
@@ -64,6 +76,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         dx = tap % 3 - 1;
     }
     const int per = p.h * p.w;
+
+    // Branch-free loads through buffer descriptors based just before this workgroup's first pixel
+    // (small 32-bit offsets whatever the tensor size); rows or taps outside the image, pixels past
+    // the chunk and channels past the tile get an out-of-range offset and read as zeros. The
+    // transposed-conv gather addresses dY by absolute offsets (the host checks it is < 2 GiB).
+    const long long pixels = static_cast<long long>(p.batch) * per;
+    long long base_pix = static_cast<long long>(k_begin) - p.w - 1;
+    if (base_pix < 0) base_pix = 0;
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b + base_pix * p.ldb, (pixels - base_pix) * p.ldb * 4ll);
+    const long long a_pixels = static_cast<long long>(p.batch) * p.a_h * p.a_w;
+    const long long a_base = MODE == WG_CONVT ? 0 : base_pix;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a + a_base * p.lda, (a_pixels - a_base) * p.lda * 4ll);
+    const int base_i = static_cast<int>(base_pix);
+
+    // this thread's tile rows are row0 + RSTEP*i; its channel quad is fixed
+    const int row0 = tid / F4R, c4 = tid % F4R;
+    const unsigned ca = m0 + c4 * 4 < p.m_total ? static_cast<unsigned>(m0 + c4 * 4) * 4u : OOB;
+    const unsigned cb = n0 + c4 * 4 < p.n_total ? static_cast<unsigned>(n0 + c4 * 4) * 4u : OOB;
+    // (sample, pixel-in-image) of each row, advanced by BKP per step without divisions;
+    // y = rem / w by multiplication with ceil(2^32 / w), exact for rem * w < 2^32.
+    const unsigned inv_w = static_cast<unsigned>((0x100000000ull + p.w - 1) / p.w);
+    int rb[LPT], rrem[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int pk = k_begin + row0 + RSTEP * i;
+        rb[i] = pk / per;
+        rrem[i] = pk - rb[i] * per;
+    }
 
     f32x16 acc[TT][TT];
 #pragma unroll
@@ -74,32 +114,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     f32x4 areg[LPT], breg[LPT];
-    auto load_global = [&](int k0) {
+    auto load_global = [&](int k0) {   // must be called with k0 = k_begin, k_begin + BKP, ... in order
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            const int f = tid + 256 * i;
-            const int row = f / F4R, c4 = f % F4R;
-            const int pk = k0 + row;
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-            if (pk < k_end) {
-                const int bi = pk / per;
-                const int rem = pk - bi * per;
-                const int y = rem / p.w, x = rem - y * p.w;
-                const int ca = m0 + c4 * 4, cb = n0 + c4 * 4;
-                if (MODE == WG_CONVT) {
-                    const int oy = 2 * y + (tap >> 1) + p.off_y, ox = 2 * x + (tap & 1) + p.off_x;
-                    if (ca < p.m_total && oy >= 0 && oy < p.a_h && ox >= 0 && ox < p.a_w)
-                        va = *reinterpret_cast<const f32x4*>(p.a + ((static_cast<int64_t>(bi) * p.a_h + oy) * p.a_w + ox) * p.lda + ca);
-                    if (cb < p.n_total) vb = *reinterpret_cast<const f32x4*>(p.b + static_cast<int64_t>(pk) * p.ldb + cb);
-                } else {
-                    if (ca < p.m_total) va = *reinterpret_cast<const f32x4*>(p.a + static_cast<int64_t>(pk) * p.lda + ca);
-                    const int yy = y + dy, xx = x + dx;
-                    if (cb < p.n_total && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w)
-                        vb = *reinterpret_cast<const f32x4*>(p.b + (static_cast<int64_t>(pk) + dy * p.w + dx) * p.ldb + cb);
-                }
+            const int pk = k0 + row0 + RSTEP * i;
+            const int rem = rrem[i], bi = rb[i];
+            const int y = p.w == 1 ? rem : static_cast<int>(__umulhi(static_cast<unsigned>(rem), inv_w));
+            const int x = rem - y * p.w;
+            const bool in_chunk = pk < k_end;
+            unsigned oa, ob;
+            if (MODE == WG_CONVT) {
+                const int oy = 2 * y + (tap >> 1) + p.off_y, ox = 2 * x + (tap & 1) + p.off_x;
+                const bool ok = in_chunk && oy >= 0 && oy < p.a_h && ox >= 0 && ox < p.a_w;
+                oa = ok ? static_cast<unsigned>((bi * p.a_h + oy) * p.a_w + ox) * p.lda * 4u + ca : OOB;
+                ob = in_chunk ? static_cast<unsigned>(pk - base_i) * p.ldb * 4u + cb : OOB;
+            } else {
+                oa = in_chunk ? static_cast<unsigned>(pk - base_i) * p.lda * 4u + ca : OOB;
+                const int yy = y + dy, xx = x + dx;
+                const bool ok = in_chunk && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
+                ob = ok ? static_cast<unsigned>(pk - base_i + dy * p.w + dx) * p.ldb * 4u + cb : OOB;
             }
-            areg[i] = va;
-            breg[i] = vb;
+            areg[i] = buf_load(rs_a, oa);
+            breg[i] = buf_load(rs_b, ob);
+            // advance this row by one K-step
+            int nr = rem + BKP;
+            int nb = bi;
+            while (nr >= per) {
+                nr -= per;
+                ++nb;
+            }
+            rrem[i] = nr;
+            rb[i] = nb;
         }
     };
     auto store_lds = [&](int buf) {
@@ -131,12 +176,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             for (int i = 0; i < TT; ++i) a[i] = pa[k * BT + i * 32];
 #pragma unroll
             for (int j = 0; j < TT; ++j) b[j] = pb[k * BT + j * 32];
+            if (ks == BKP / 2 - 4 && more) store_lds(buf ^ 1);   // before the last MFMAs, not after them
 #pragma unroll
             for (int i = 0; i < TT; ++i)
 #pragma unroll
                 for (int j = 0; j < TT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_lds(buf ^ 1);
         __syncthreads();
     }
 
@@ -263,6 +308,7 @@ extern "C" int ddpm_convT2x2_wgrad(const float* dy, int ldy, int cout, int out_h
     p.m_total = cout; p.lda = ldy; p.n_total = cin; p.ldb = ldx;
     p.off_y = off_y; p.off_x = off_x;
     p.taps = 4; p.k_total = batch * h * w;
+    DDPM_REQUIRE(static_cast<int64_t>(batch) * out_h * out_w * ldy * 4ll < 0x7fffffffll);   // dY is gathered by 32-bit byte offsets
     if (int rc = launch_wgrad<WG_CONVT>(p, as_stream(stream))) return rc;
     unpack_convT_kernel<<<grid_1d(4ll * cout * cin), 256, 0, as_stream(stream)>>>(packed, cout, cin, grad_w);
     return ddpm::check_launch("unpack_convT_kernel");
