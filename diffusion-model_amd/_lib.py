@@ -52,6 +52,7 @@ _SIGNATURES = {
     "ddpm_convT2x2_fwd": [C.POINTER(ConvDesc), P, P, C.POINTER(Epilogue), P, P],
     "ddpm_pack_conv3x3": [P, I32, I32, I32, P, P],
     "ddpm_pack_convT2x2": [P, I32, I32, P, P],
+    "ddpm_pack_conv1x1": [P, I32, I32, I32, P, P],
     "ddpm_conv3x3_first_fwd": [P, P, C.POINTER(Epilogue), I32, P, I32, I32, I32, I32, I32, I32, P],
     "ddpm_conv1x1_final_fwd": [P, I32, P, P, P, I32, I32, I32, I32, I32, P],
     "ddpm_pool_skip_fwd": [P, I32, P, P, I32, P, I32, P, I32, I32, I32, I32, P],
@@ -92,6 +93,8 @@ def lib():
         handle.ddpm_last_error.argtypes = []
         handle.ddpm_reduce_workspace_doubles.restype = C.c_int64
         handle.ddpm_reduce_workspace_doubles.argtypes = [I32]
+        handle.ddpm_packed_weight_floats.restype = C.c_int64
+        handle.ddpm_packed_weight_floats.argtypes = [I32, I32, I32]
         for name, sig in _SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the header and library disagree
             fn.argtypes = sig
@@ -101,7 +104,12 @@ def lib():
 
 
 def exported_symbols():
-    return ["ddpm_last_error", "ddpm_reduce_workspace_doubles"] + list(_SIGNATURES)
+    return ["ddpm_last_error", "ddpm_reduce_workspace_doubles", "ddpm_packed_weight_floats"] + list(_SIGNATURES)
+
+
+def packed_floats(taps, rows, cin):
+    """Size, in floats, of the packed weight buffer of a (taps x rows x cin) contraction."""
+    return int(lib().ddpm_packed_weight_floats(taps, rows, cin))
 
 
 def call(name, *args):

@@ -24,6 +24,8 @@
 // the chunk is complete after four MFMAs. Accumulator: column = lane & 31,
 // row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5). The 4 waves form a 2 x 2 grid; row group g of a
 // tile belongs to wave row g & 1 (slot g >> 1), so a short tile keeps both wave rows busy.
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "common.h"
@@ -69,6 +71,7 @@ struct GemmParams {
     int n_tiles, groups_total, gpb;
     long long src1_pixels, src2_pixels;  // pixels (rows of ld floats) in each source tensor
     unsigned w_bytes;
+    int kc16;                            // 16-channel chunks per tap (split-bf16 path)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -353,13 +356,329 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
     }
 }
 
+
+// ---- split-bf16 variant ---------------------------------------------------------------------
+// Every fp32 operand is written as the exact sum of three bf16 numbers (hi + mid + lo: truncation
+// splits, 8 significant bits each, 24 in total), and a fp32 product a*b is evaluated as the six
+// cross products of weight >= 2^-16 (hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi) on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three dropped products are below 2^-23 of
+// a*b, the size of one fp32 rounding. Six bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64
+// cycles per 16-deep slice: 2.67x the matrix throughput at fp32 accuracy.
+//
+// The bf16 MFMA truncates (rounds toward zero) when it accumulates, which biases long sums of
+// like-signed terms; the K loop therefore accumulates at most 4 steps (64 input channels of one tap)
+// in the MFMA accumulator and folds that partial sum into a master accumulator with a
+// round-to-nearest fp32 add.
+//
+// Activations are split in registers on their way from global memory to LDS; weights arrive already
+// split from the packing kernels: [tap][row][chunk of 16 channels][plane hi|mid|lo][16] bf16.
+// LDS tile rows hold the three planes of one 16-deep slice (3 x 32 B) padded to 112 B, which makes the
+// 16-byte fragment reads (lane = row) conflict-free. Loads run two steps ahead of the MFMAs: the data
+// of step s+2 is requested during step s, split and written to LDS during step s+1.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int XK = 16;      // channels per K step
+constexpr int XROW = 112;   // LDS bytes per tile row
+constexpr int XFLUSH = 4;   // steps between folds into the master accumulator
+
+__device__ __forceinline__ void split_store(const f32x4 v, unsigned char* dst) {
+    unsigned u[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        u[e] = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(u[e] & 0xffff0000u);
+        m[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(m[e] & 0xffff0000u);
+        l[e] = __float_as_uint(r2);
+    }
+    // upper halves of two dwords -> one dword of two bf16 (element 0 in the low half)
+    u32x2 hi, mid, lo;
+    hi[0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
+    hi[1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
+    mid[0] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
+    mid[1] = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
+    lo[0] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
+    lo[1] = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
+    *reinterpret_cast<u32x2*>(dst) = hi;
+    *reinterpret_cast<u32x2*>(dst + 32) = mid;
+    *reinterpret_cast<u32x2*>(dst + 64) = lo;
+}
+
+template <int BN, int MODE, bool DUAL>
+__global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p) {
+    constexpr int TN = BN / 64;               // 32-column MFMA tiles per wave (2 x 2 waves)
+    constexpr int NB = (BN * 6 + 255) / 256;  // 16-byte weight pieces per thread and step
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * XROW];
+    __shared__ int4 rowinfo[BM];
+
+    const int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
+        id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+    }
+    const int n_tile = id % p.n_tiles;
+    const int m_block = id / p.n_tiles;
+    const int n0 = n_tile * BN;
+    const int g_begin = m_block * p.gpb;
+    const int g_end = min(p.groups_total, g_begin + p.gpb);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int lrow = tid >> 2, lq = tid & 3;   // activation staging: row (and row + 64), 4-channel quad
+
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+    // weight pieces of this thread: piece k of a row is plane k/2, half k%2 of the row's 96 bytes
+    unsigned wrow[NB];
+    int wlds[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / 6, piece = idx - row * 6;
+        const int n = n0 + row;
+        wrow[i] = (row < BN && n < p.n_total) ? (static_cast<unsigned>(n) * p.kc16 * 96u + piece * 16u) : OOB;
+        wlds[i] = row < BN ? row * XROW + piece * 16 : -1;
+    }
+    const unsigned tap_stride_w = static_cast<unsigned>(p.n_total) * p.kc16 * 96u;
+    const int steps = p.taps * p.kc16;
+
+    for (int g0 = g_begin; g0 < g_end; g0 += 4) {
+        const int kg = min(4, g_end - g0);
+        const int m0 = g0 * 32;
+
+        __syncthreads();
+        if (tid < BM) {
+            const int m = m0 + tid;
+            int4 info = make_int4(-1, 0, 0, 0);
+            if (tid < kg * 32 && m < p.m_total) {
+                const int per = p.win_h * p.win_w;
+                const int b = m / per;
+                const int rem = m - b * per;
+                const int wy = rem / p.win_w;
+                const int y = p.win_y0 + wy, x = p.win_x0 + (rem - wy * p.win_w);
+                info = make_int4((b * p.in_h + y) * p.in_w + x, b, y, x);
+            }
+            rowinfo[tid] = info;
+        }
+        __syncthreads();
+
+        int4 ri[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ri[i] = rowinfo[lrow + 64 * i];
+
+        long long pix0 = 0;
+        if (MODE != MODE_CONVT_DGRAD) {
+            const int first = __builtin_amdgcn_readfirstlane(rowinfo[0].x);
+            pix0 = first - p.in_w - 1;
+            if (pix0 < 0) pix0 = 0;
+        }
+        const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.src1 + pix0 * p.ld1, (p.src1_pixels - pix0) * p.ld1 * 4ll);
+        const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(p.src2 + pix0 * p.ld2, (p.src2_pixels - pix0) * p.ld2 * 4ll);
+        const int pix0i = static_cast<int>(pix0);
+
+        unsigned aoff1[2], aoff2[2];
+        auto set_tap = [&](int tap) {
+            int dy = 0, dx = 0;
+            if (MODE == MODE_CONV3) {
+                dy = tap / 3 - 1;
+                dx = tap - (tap / 3) * 3 - 1;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bool ok = ri[i].x >= 0;
+                int rel;
+                if (MODE == MODE_CONVT_DGRAD) {
+                    const int oy = 2 * ri[i].z + (tap >> 1) + p.off_y, ox = 2 * ri[i].w + (tap & 1) + p.off_x;
+                    ok = ok && oy >= 0 && oy < p.out_h && ox >= 0 && ox < p.out_w;
+                    rel = (ri[i].y * p.out_h + oy) * p.out_w + ox;
+                } else {
+                    const int yy = ri[i].z + dy, xx = ri[i].w + dx;
+                    ok = ok && yy >= 0 && yy < p.in_h && xx >= 0 && xx < p.in_w;
+                    rel = ri[i].x - pix0i + dy * p.in_w + dx;
+                }
+                aoff1[i] = ok ? static_cast<unsigned>(rel) * p.ld1 * 4u : OOB;
+                if (DUAL) aoff2[i] = ok ? static_cast<unsigned>(rel) * p.ld2 * 4u : OOB;
+            }
+        };
+
+        f32x4 areg[2];
+        u32x4 breg[NB];
+        int ltap = 0, lkc = 0;   // (tap, chunk) of the next stage to request
+        auto load_stage = [&]() {
+            const int c = lkc * XK + lq * 4;
+            const unsigned cb = c < p.ctot ? static_cast<unsigned>(c) * 4u : OOB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (DUAL) {
+                    const unsigned o1 = c < p.c1 ? aoff1[i] + cb : OOB;
+                    const unsigned o2 = (c >= p.c1 && c < p.ctot) ? aoff2[i] + static_cast<unsigned>(c - p.c1) * 4u : OOB;
+                    areg[i] = buf_load(rs1, o1) + buf_load(rs2, o2);
+                } else {
+                    areg[i] = buf_load(rs1, aoff1[i] + cb);
+                }
+            }
+            const unsigned tb = static_cast<unsigned>(ltap) * tap_stride_w + static_cast<unsigned>(lkc) * 96u;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) breg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wrow[i] + tb, 0, 0);
+            if (++lkc == p.kc16) {
+                lkc = 0;
+                ++ltap;
+                if (ltap < p.taps) set_tap(ltap);
+            }
+        };
+        auto store_stage = [&](int buf) {
+            unsigned char* sA = smem[buf];
+            unsigned char* sB = smem[buf] + BM * XROW;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) split_store(areg[i], sA + (lrow + 64 * i) * XROW + lq * 8);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                if (NB * 256 == BN * 6 || wlds[i] >= 0) *reinterpret_cast<u32x4*>(sB + wlds[i]) = breg[i];
+        };
+
+        f32x16 master[2][TN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) master[i][j][e] = 0.f;
+
+        set_tap(0);
+        load_stage();
+        store_stage(0);
+        if (steps > 1) load_stage();
+        __syncthreads();
+
+        const int my_slots = (kg - wm + 1) >> 1;
+        auto k_loop = [&](auto slots_tag) {
+            constexpr int SLOTS = decltype(slots_tag)::value;
+            constexpr int SL = SLOTS > 0 ? SLOTS : 1;
+            f32x16 acc[SL][TN];
+#pragma unroll
+            for (int i = 0; i < SL; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int s = 0; s < steps; ++s) {
+                const int buf = s & 1;
+                if (SLOTS > 0) {
+                    const unsigned char* sA = smem[buf] + (wm * 32 + r) * XROW + h * 16;
+                    const unsigned char* sB = smem[buf] + BM * XROW + (wn * TN * 32 + r) * XROW + h * 16;
+                    bf16x8 a[SL][3], b[TN][3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) b[j][pl] = *reinterpret_cast<const bf16x8*>(sB + j * 32 * XROW + pl * 32);
+#pragma unroll
+                        for (int i = 0; i < SL; ++i) a[i][pl] = *reinterpret_cast<const bf16x8*>(sA + i * 64 * XROW + pl * 32);
+                    }
+                    auto term = [&](int pa, int pb) {
+#pragma unroll
+                        for (int i = 0; i < SL; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+                    };
+                    // smallest products first
+                    term(2, 0);
+                    term(0, 2);
+                    term(1, 1);
+                    if (s + 1 < steps) store_stage(buf ^ 1);
+                    if (s + 2 < steps) load_stage();
+                    term(1, 0);
+                    term(0, 1);
+                    term(0, 0);
+                    if ((s & (XFLUSH - 1)) == XFLUSH - 1 || s + 1 == steps) {
+#pragma unroll
+                        for (int i = 0; i < SL; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) {
+                                master[i][j] += acc[i][j];
+#pragma unroll
+                                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                            }
+                    }
+                } else {
+                    if (s + 1 < steps) store_stage(buf ^ 1);
+                    if (s + 2 < steps) load_stage();
+                }
+                __syncthreads();
+            }
+        };
+        using T0 = std::integral_constant<int, 0>;
+        using T1 = std::integral_constant<int, 1>;
+        using T2 = std::integral_constant<int, 2>;
+        if (my_slots == 2) k_loop(T2{});
+        else if (my_slots == 1) k_loop(T1{});
+        else k_loop(T0{});
+
+        // ---- epilogue ---------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + r;
+            if (n >= p.n_total) continue;
+            int co = n, qa = 0, qb = 0;
+            if (MODE == MODE_CONVT) {
+                const int q = n / p.cout;
+                co = n - q * p.cout;
+                qa = q >> 1;
+                qb = q & 1;
+            }
+            const float sc = p.scale ? p.scale[co] : 1.0f;
+            const float sh = p.shift ? p.shift[co] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i >= my_slots) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (i * 2 + wm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int4 info = rowinfo[row];
+                    if (info.x < 0) continue;
+                    float v = master[i][j][e] * sc + sh;
+                    if (MODE == MODE_CONVT) {
+                        const int oy = 2 * info.z + qa + p.off_y, ox = 2 * info.w + qb + p.off_x;
+                        if (oy < 0 || oy >= p.out_h || ox < 0 || ox >= p.out_w) continue;
+                        const int64_t opix = (static_cast<int64_t>(info.y) * p.out_h + oy) * p.out_w + ox;
+                        p.out[opix * p.ldo + co] = v;
+                    } else {
+                        const int64_t pix = info.x;
+                        if (p.residual) v += p.residual[pix * p.ldr + n];
+                        v = apply_act(v, p.act);
+                        if (p.temb) v += p.temb[static_cast<int64_t>(info.y) * p.cout + n];
+                        p.out[pix * p.ldo + n] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// DDPM_CONV_MATH=fp32 in the environment (read once) selects the plain fp32 MFMA kernels and the
+// fp32 packed-weight format instead of the split-bf16 ones: a diagnostic switch for A/B measurements.
+bool split_math() {
+    static const bool on = [] {
+        const char* e = getenv("DDPM_CONV_MATH");
+        return !(e && strcmp(e, "fp32") == 0);
+    }();
+    return on;
+}
+
 template <int MODE>
 int launch_gemm(GemmParams& p, hipStream_t s) {
     // Column tile and run length: minimise (row groups per workgroup) x (columns per tile), the time
     // of the busiest workgroup when the whole grid is one resident round. The 64-column tile stages
     // as many activation bytes for half the MFMA work, and measures ~35 % slower per FLOP, hence the handicap.
+    const bool x3 = split_math();
     p.groups_total = (p.m_total + 31) / 32;
-    const long long wb = 4ll * p.taps * p.n_total * p.ctot;
+    p.kc16 = (p.ctot + XK - 1) / XK;
+    const long long wb = x3 ? 96ll * p.taps * p.n_total * p.kc16 : 4ll * p.taps * p.n_total * p.ctot;
     if (wb >= 0x7fffffffll) return ddpm::fail_invalid("weight tensor of 2 GiB or more");
     p.w_bytes = static_cast<unsigned>(wb);
     int best_bn = 0, best_gpb = 0;
@@ -382,6 +701,16 @@ int launch_gemm(GemmParams& p, hipStream_t s) {
     if (grid <= 0 || grid > 0x7fffffffll) return ddpm::fail_invalid("conv grid size");
     const dim3 g(static_cast<unsigned>(grid)), b(256);
     const bool dual = p.c2 > 0;
+    if (x3) {
+        if (best_bn == 128) {
+            if (dual) conv_gemm_x3_kernel<128, MODE, true><<<g, b, 0, s>>>(p);
+            else conv_gemm_x3_kernel<128, MODE, false><<<g, b, 0, s>>>(p);
+        } else {
+            if (dual) conv_gemm_x3_kernel<64, MODE, true><<<g, b, 0, s>>>(p);
+            else conv_gemm_x3_kernel<64, MODE, false><<<g, b, 0, s>>>(p);
+        }
+        return ddpm::check_launch("conv_gemm_x3_kernel");
+    }
     if (best_bn == 128) {
         if (dual) conv_gemm_kernel<128, MODE, true><<<g, b, 0, s>>>(p);
         else conv_gemm_kernel<128, MODE, false><<<g, b, 0, s>>>(p);
@@ -488,7 +817,90 @@ __global__ void pack_convT_dgrad_kernel(const float* __restrict__ w, int cin, in
     }
 }
 
+
+// Split-bf16 packing: logical weight W(tap, n, c) = w[base + tap*st + (n / nq)*sq + (n % nq)*sn + c*sc]
+// -> out[tap][n][c / 16][plane][c % 16] (bf16, planes hi | mid | lo, channels padded with zeros to a
+// multiple of 16).
+struct SplitPack {
+    const float* w;
+    unsigned short* out;
+    int taps, rows, cin, kc16, nq;
+    long long base, st, sq, sn, sc;
+};
+
+__global__ void pack_split_kernel(const SplitPack a) {
+    const int64_t total = static_cast<int64_t>(a.taps) * a.rows * a.kc16 * 16;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int e = static_cast<int>(i & 15);
+        const int64_t chunk = i >> 4;                       // (tap*rows + n)*kc16 + kc
+        const int kc = static_cast<int>(chunk % a.kc16);
+        const int64_t tn = chunk / a.kc16;
+        const int n = static_cast<int>(tn % a.rows);
+        const int tap = static_cast<int>(tn / a.rows);
+        const int c = kc * 16 + e;
+        float v = 0.f;
+        if (c < a.cin) v = a.w[a.base + tap * a.st + (n / a.nq) * a.sq + (n % a.nq) * a.sn + c * a.sc];
+        const unsigned u = __float_as_uint(v);
+        const float r1 = v - __uint_as_float(u & 0xffff0000u);
+        const unsigned m = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(m & 0xffff0000u);
+        unsigned short* o = a.out + chunk * 48 + e;
+        o[0] = static_cast<unsigned short>(u >> 16);
+        o[16] = static_cast<unsigned short>(m >> 16);
+        o[32] = static_cast<unsigned short>(__float_as_uint(r2) >> 16);
+    }
+}
+
+int launch_split_pack(const float* w, float* out, int taps, int rows, int cin, int nq, long long base, long long st,
+                      long long sq, long long sn, long long sc, hipStream_t s) {
+    SplitPack a;
+    a.w = w;
+    a.out = reinterpret_cast<unsigned short*>(out);
+    a.taps = taps;
+    a.rows = rows;
+    a.cin = cin;
+    a.kc16 = (cin + 15) / 16;
+    a.nq = nq;
+    a.base = base;
+    a.st = st;
+    a.sq = sq;
+    a.sn = sn;
+    a.sc = sc;
+    const int64_t total = static_cast<int64_t>(taps) * rows * a.kc16 * 16;
+    const int grid = static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    pack_split_kernel<<<grid, 256, 0, s>>>(a);
+    return ddpm::check_launch("pack_split_kernel");
+}
+
+__global__ void copy_transpose_kernel(const float* __restrict__ w, int rows, int cin, int transpose, float* __restrict__ out) {
+    const int64_t total = static_cast<int64_t>(rows) * cin;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int c = static_cast<int>(i % cin);
+        const int n = static_cast<int>(i / cin);
+        out[i] = transpose ? w[static_cast<int64_t>(c) * rows + n] : w[i];
+    }
+}
+
 }  // namespace
+
+extern "C" int64_t ddpm_packed_weight_floats(int taps, int rows, int cin) {
+    if (taps <= 0 || rows <= 0 || cin <= 0) return 0;
+    if (!split_math()) return static_cast<int64_t>(taps) * rows * cin;
+    return static_cast<int64_t>(taps) * rows * ((cin + 15) / 16) * 24;   // 96 bytes per 16-channel chunk
+}
+
+extern "C" int ddpm_pack_conv1x1(const float* w, int rows, int cin, int transpose, float* out, void* stream) {
+    DDPM_REQUIRE(w && out && rows > 0 && cin > 0);
+    if (split_math())
+        return transpose ? launch_split_pack(w, out, 1, rows, cin, rows, 0, 0, 0, 1, rows, as_stream(stream))
+                         : launch_split_pack(w, out, 1, rows, cin, rows, 0, 0, 0, cin, 1, as_stream(stream));
+    const int64_t total = static_cast<int64_t>(rows) * cin;
+    const int grid = static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    copy_transpose_kernel<<<grid, 256, 0, as_stream(stream)>>>(w, rows, cin, transpose, out);
+    return ddpm::check_launch("copy_transpose_kernel");
+}
 
 extern "C" int ddpm_conv3x3_fwd(const ddpm_conv_desc* d, const float* src1, const float* src2, const float* w_packed,
                                 const ddpm_epilogue* ep, float* out, void* stream) {
@@ -545,6 +957,9 @@ extern "C" int ddpm_convT2x2_fwd(const ddpm_conv_desc* d, const float* src, cons
 
 extern "C" int ddpm_pack_conv3x3(const float* w, int cout, int cin, int flip, float* out, void* stream) {
     DDPM_REQUIRE(w && out && cout > 0 && cin > 0);
+    if (split_math())   // rows = cout, depth = cin; flipped: rows = cin, depth = cout, tap mirrored
+        return flip ? launch_split_pack(w, out, 9, cin, cout, cin, 8, -1, 0, 9, 9ll * cin, as_stream(stream))
+                    : launch_split_pack(w, out, 9, cout, cin, cout, 0, 1, 0, 9ll * cin, 9, as_stream(stream));
     const int64_t total = static_cast<int64_t>(cout) * cin * 9;
     const int grid = static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     pack_conv3x3_kernel<<<grid, 256, 0, as_stream(stream)>>>(w, cout, cin, flip, out);
@@ -553,6 +968,8 @@ extern "C" int ddpm_pack_conv3x3(const float* w, int cout, int cin, int flip, fl
 
 extern "C" int ddpm_pack_convT2x2(const float* w, int cin, int cout, float* out, void* stream) {
     DDPM_REQUIRE(w && out && cout > 0 && cin > 0);
+    if (split_math())   // row q*cout + co, depth ci: w[ci][co][q]
+        return launch_split_pack(w, out, 1, 4 * cout, cin, cout, 0, 0, 1, 4, 4ll * cout, as_stream(stream));
     const int64_t total = static_cast<int64_t>(cout) * cin * 4;
     const int grid = static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     pack_convT_kernel<<<grid, 256, 0, as_stream(stream)>>>(w, cin, cout, out);
@@ -561,6 +978,8 @@ extern "C" int ddpm_pack_convT2x2(const float* w, int cin, int cout, float* out,
 
 extern "C" int ddpm_pack_convT2x2_dgrad(const float* w, int cin, int cout, float* out, void* stream) {
     DDPM_REQUIRE(w && out && cout > 0 && cin > 0);
+    if (split_math())   // tap q, row ci, depth co: w[ci][co][q]
+        return launch_split_pack(w, out, 4, cin, cout, cin, 0, 1, 0, 4ll * cout, 4, as_stream(stream));
     const int64_t total = static_cast<int64_t>(cout) * cin * 4;
     const int grid = static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     pack_convT_dgrad_kernel<<<grid, 256, 0, as_stream(stream)>>>(w, cin, cout, out);

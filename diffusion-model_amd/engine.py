@@ -13,7 +13,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, EmbedArgs, Epilogue, call
+from ._lib import ConvDesc, EmbedArgs, Epilogue, call, packed_floats
 from .engine_train import TrainMixin, UNetFunction
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
@@ -26,6 +26,14 @@ def _ptr(t):
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pack_1x1(w, transpose):
+    """[rows][cin] fp32 weight of a 1x1 conv (or its transpose: the data-gradient GEMM) -> the library's packed layout."""
+    rows, cin = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+    out = torch.empty(packed_floats(1, rows, cin), device=w.device, dtype=torch.float32)
+    call("ddpm_pack_conv1x1", _ptr(w.contiguous()), rows, cin, int(transpose), _ptr(out), _stream())
+    return out
 
 
 def _round_up(a, b):
@@ -143,14 +151,15 @@ class UNetEngine(TrainMixin):
 
     def packed_conv3(self, key, flip=False):
         def build(w):
-            out = torch.empty(9 * w.shape[0] * w.shape[1], device=w.device, dtype=torch.float32)
+            rows, depth = (w.shape[1], w.shape[0]) if flip else (w.shape[0], w.shape[1])
+            out = torch.empty(packed_floats(9, rows, depth), device=w.device, dtype=torch.float32)
             call("ddpm_pack_conv3x3", _ptr(w.detach().contiguous()), w.shape[0], w.shape[1], int(flip), _ptr(out), _stream())
             return out
         return self._cached("pk3f" if flip else "pk3", (key + ".weight",), build)
 
     def packed_convT(self, key):
         def build(w):
-            out = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+            out = torch.empty(packed_floats(1, 4 * w.shape[1], w.shape[0]), device=w.device, dtype=torch.float32)
             call("ddpm_pack_convT2x2", _ptr(w.detach().contiguous()), w.shape[0], w.shape[1], _ptr(out), _stream())
             return out
         return self._cached("pkT", (key + ".weight",), build)
@@ -165,7 +174,8 @@ class UNetEngine(TrainMixin):
         return self._cached("fold", keys, build)
 
     def packed_qkv(self, key):
-        """[2*dqp + C][C] weight and [2*dqp + C] bias; q and k zero-padded to dqp = round_up(C/8, 8) rows."""
+        """Fused q|k|v projection: packed [2*dqp + C][C] weight, [2*dqp + C] bias, dqp, and the packed transpose
+        (for the data gradient); q and k zero-padded to dqp = round_up(C/8, 8) rows."""
         def build(qw, qb, kw, kb, vw, vb):
             c = vw.shape[0]
             dq = qw.shape[0]
@@ -176,7 +186,7 @@ class UNetEngine(TrainMixin):
             w[dqp:dqp + dq] = kw.reshape(dq, c)
             w[2 * dqp:] = vw.reshape(c, c)
             b[:dq], b[dqp:dqp + dq], b[2 * dqp:] = qb, kb, vb
-            return w, b, dqp
+            return pack_1x1(w, False), b, dqp, pack_1x1(w, True)
         keys = tuple(f"{key}.{n}.{s}" for n in ("query", "key", "value") for s in ("weight", "bias"))
         return self._cached("qkv", keys, build)
 
@@ -300,7 +310,7 @@ class UNetEngine(TrainMixin):
     def attention(self, x, key, out, temb=None, save=None):
         b, h, w = x.bhw
         c = x.c
-        wq, bq, dqp = self.packed_qkv(key)
+        wq, bq, dqp, _ = self.packed_qkv(key)
         if dqp not in (8, 16, 32, 64):
             raise NotImplementedError(f"attention with C/8 = {c // 8} query channels is not supported")
         qkv = View(self._new(b, h, w, 2 * dqp + c, x.buf))

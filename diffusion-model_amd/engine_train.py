@@ -10,7 +10,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import ConvDesc, EmbedArgs, EmbedBwdArgs, Epilogue, call, lib
+from ._lib import ConvDesc, EmbedArgs, EmbedBwdArgs, Epilogue, call, lib, packed_floats
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -206,7 +206,7 @@ class TrainMixin:
         b, h, w = x.bhw
         c, n = x.c, h * w
         dev = x.buf.device
-        wq, bq, dqp = self.packed_qkv(key)
+        _, bq, dqp, wt = self.packed_qkv(key)
         lq = 2 * dqp + c
         dq = c // 8
         dqkv = V(torch.empty((b, h, w, lq), device=dev, dtype=torch.float32))
@@ -226,8 +226,6 @@ class TrainMixin:
             grads[f"{key}.{name}.weight"] = gw[lo:lo + cnt].reshape(self.T(f"{key}.{name}.weight").shape)
             grads[f"{key}.{name}.bias"] = gb[lo:lo + cnt]
         # dx = dqkv @ Wqkv + dout   (1x1 conv with the transposed weight, residual = pass-through gradient)
-        wt = self._cached("qkvT", tuple(f"{key}.{nm}.{s}" for nm in ("query", "key", "value") for s in ("weight", "bias")),
-                          lambda *ts: self.packed_qkv(key)[0].t().contiguous())
         dx = V(torch.empty((b, h, w, c), device=dev, dtype=torch.float32))
         d = ConvDesc(batch=b, in_h=h, in_w=w, c1=lq, ld1=lq, c2=0, ld2=0, cout=c, ldo=c, act=ACT_NONE, ldr=dout.ld, out_h=h, out_w=w,
                      off_y=0, off_x=0)
@@ -345,7 +343,7 @@ class TrainMixin:
         return grads
 
     def _pack_convT_dgrad(self, wt):
-        out = torch.empty(wt.numel(), device=wt.device, dtype=torch.float32)
+        out = torch.empty(packed_floats(4, wt.shape[0], wt.shape[1]), device=wt.device, dtype=torch.float32)
         call("ddpm_pack_convT2x2_dgrad", _ptr(wt.detach().contiguous()), wt.shape[0], wt.shape[1], _ptr(out), _stream())
         return out
 

@@ -119,8 +119,11 @@ int ddpm_time_embed(const ddpm_embed_args* a, void* stream);
 int ddpm_sinusoidal_embedding(const void* t, int t_is_float, int batch, int emb_dim, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * Convolutions as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32), LDS-staged tiles.
+ * Convolutions as implicit GEMM on the matrix cores, LDS-staged tiles.
  * rows = pixels, columns = output channels, K = taps * input channels.
+ * Arithmetic: each fp32 operand is split exactly into three bf16 terms and a product is the sum of
+ * the six cross terms of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16, accumulated in fp32 (error per
+ * product below 2^-23, i.e. fp32 grade; see conv_gemm.hip).
  * ------------------------------------------------------------------------------------- */
 typedef struct ddpm_conv_desc {
     int32_t batch, in_h, in_w;       /* input geometry */
@@ -149,31 +152,40 @@ typedef struct ddpm_epilogue {
     const float* temb;
 } ddpm_epilogue;
 
-/* 3x3, padding 1, stride 1. w_packed: [9][cout][c1+c2] (see ddpm_pack_conv3x3).
+/* 3x3, padding 1, stride 1. w_packed from ddpm_pack_conv3x3 (cin = c1+c2).
  * Replaces nn.Conv2d(k=3,p=1) (+ eval BatchNorm2d + ReLU/GELU + residual + time-embedding add):
  * first-iteration/unet.py:16-21, second-iteration/unet.py:16-21,26,32-36.
  * Requires c1 % 4 == c2 % 4 == ld % 4 == 0. */
 int ddpm_conv3x3_fwd(const ddpm_conv_desc* d, const float* src1, const float* src2,
                      const float* w_packed, const ddpm_epilogue* ep, float* out, void* stream);
 
-/* 1x1. w_packed: [cout][c1+c2]. Replaces the query/key/value projections
+/* 1x1. w_packed from ddpm_pack_conv1x1 (rows = cout, cin = c1+c2). Replaces the query/key/value projections
  * (second-iteration/unet.py:45-47,52-57) as ONE GEMM with cout = 2*(C/8) + C. */
 int ddpm_conv1x1_fwd(const ddpm_conv_desc* d, const float* src1, const float* src2,
                      const float* w_packed, const ddpm_epilogue* ep, float* out, void* stream);
 
 /* ConvTranspose2d(k=2, s=2) followed by F.pad/crop to (out_h, out_w): output pixel
- * (2y+a+off_y, 2x+b+off_x), dropped when outside. w_packed: [4*cout][c1] with row
- * (a*2+b)*cout + co; shift = bias[co] (length cout). Only input pixels whose outputs survive the
+ * (2y+a+off_y, 2x+b+off_x), dropped when outside. w_packed from ddpm_pack_convT2x2;
+ * shift = bias[co] (length cout). Only input pixels whose outputs survive the
  * crop are computed. Replaces first-iteration/unet.py:41,45-48. */
 int ddpm_convT2x2_fwd(const ddpm_conv_desc* d, const float* src, const float* w_packed,
                       const ddpm_epilogue* ep, float* out, void* stream);
 
-/* Weight repacking (device -> device), torch layouts in:
- *   conv3x3: [cout][cin][3][3] -> [9][cout][cin]; flip=1 additionally swaps the roles for the
- *            data-gradient conv: out[tap'][ci][co] = w[co][ci][8-tap'] (a 3x3 conv of dY).
- *   convT:   [cin][cout][2][2] -> [4*cout][cin]. */
+/* Weight repacking (device -> device) from torch's parameter layouts into the library's packed
+ * layout, an opaque buffer of ddpm_packed_weight_floats(taps, rows, cin) floats for a contraction of
+ * `taps` taps, `rows` GEMM columns (output channels) and `cin` input channels:
+ *   conv3x3: [cout][cin][3][3] -> taps 9, rows cout, depth cin; flip=1 packs the data-gradient conv
+ *            instead (a 3x3 conv of dY): taps 9, rows cin, depth cout, W'(tap, ci, co) = w[co][ci][8-tap].
+ *   convT:   [cin][cout][2][2] -> taps 1, rows 4*cout (row (a*2+b)*cout + co), depth cin.
+ *   conv1x1: [rows][cin] (transpose=0) or its transpose [cin][rows] (transpose=1, the data-gradient
+ *            GEMM of a 1x1 conv) -> taps 1.
+ * Contents: every weight as an exact sum of three bf16 numbers (hi + mid + lo), laid out
+ * [tap][row][cin/16][plane][16] with the channels zero-padded to a multiple of 16; with
+ * DDPM_CONV_MATH=fp32 in the environment (diagnostic: plain fp32 MFMA kernels) fp32 [tap][row][cin]. */
+int64_t ddpm_packed_weight_floats(int taps, int rows, int cin);
 int ddpm_pack_conv3x3(const float* w, int cout, int cin, int flip, float* out, void* stream);
 int ddpm_pack_convT2x2(const float* w, int cin, int cout, float* out, void* stream);
+int ddpm_pack_conv1x1(const float* w, int rows, int cin, int transpose, float* out, void* stream);
 
 /* First layer: 3x3 pad 1 on an NCHW input with few channels (1 or 3), direct (non-MFMA),
  * writes NHWC with the same epilogue. w: torch layout [cout][cin][3][3].

@@ -3,7 +3,7 @@ import ctypes as C
 
 import torch
 
-from diffusion_model_amd._lib import ConvDesc, Epilogue, call  # noqa: F401
+from diffusion_model_amd._lib import ConvDesc, Epilogue, call, packed_floats  # noqa: F401
 
 
 _keepalive = []

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 from diffusion_model_amd import _lib
 from diffusion_model_amd._lib import EmbedBwdArgs
-from gpu_util import ConvDesc, Epilogue, P, assert_close, call, from_nhwc, rnd, stream, to_nhwc
+from gpu_util import ConvDesc, Epilogue, P, assert_close, call, from_nhwc, packed_floats, rnd, stream, to_nhwc
 
 pytestmark = pytest.mark.gpu
 TOL = 3e-5
@@ -86,7 +86,8 @@ def test_colsum_groups(case):
 
 
 def pack3(w, flip):
-    out = torch.empty(w.numel(), device="cuda")
+    rows, depth = (w.shape[1], w.shape[0]) if flip else (w.shape[0], w.shape[1])
+    out = torch.empty(packed_floats(9, rows, depth), device="cuda")
     call("ddpm_pack_conv3x3", P(w.cuda().contiguous()), w.shape[0], w.shape[1], flip, P(out), stream())
     return out
 
@@ -125,7 +126,8 @@ def test_conv1x1_bwd(case):
     dx = torch.empty((B, N, 1, ci), device="cuda")
     d = ConvDesc(batch=B, in_h=N, in_w=1, c1=co, ld1=co, c2=0, ld2=0, cout=ci, ldo=ci, act=0, ldr=0, out_h=N, out_w=1)
     ep = Epilogue(None, None, None, None)
-    wt = w.detach().t().contiguous().cuda()
+    wt = torch.empty(packed_floats(1, ci, co), device="cuda")
+    call("ddpm_pack_conv1x1", P(w.detach().cuda().contiguous()), ci, co, 1, P(wt), stream())
     call("ddpm_conv1x1_fwd", C.byref(d), P(dyd), None, P(wt), C.byref(ep), P(dx), stream())
     assert_close(from_nhwc(dx), x.grad, TOL, f"1x1 dgrad {case}")
 
@@ -143,7 +145,7 @@ def test_convT_bwd(case):
     dout = rnd((B, co, OH, OW), 4)
     yp.backward(dout)
     dd, xd = to_nhwc(dout), to_nhwc(x.detach())
-    wp = torch.empty(w.numel(), device="cuda")
+    wp = torch.empty(packed_floats(4, ci, co), device="cuda")
     call("ddpm_pack_convT2x2_dgrad", P(w.detach().cuda()), ci, co, P(wp), stream())
     dx = torch.empty((B, H, W, ci), device="cuda")
     d = ConvDesc(batch=B, in_h=H, in_w=W, c1=co, ld1=co, c2=0, ld2=0, cout=ci, ldo=ci, act=0, ldr=0, out_h=OH, out_w=OW,

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import load_golden
-from gpu_util import ConvDesc, Epilogue, P, assert_close, call, from_nhwc, rnd, stream, to_nhwc
+from gpu_util import ConvDesc, Epilogue, P, assert_close, call, from_nhwc, packed_floats, rnd, stream, to_nhwc
 from oracle import ddpm_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -131,7 +131,7 @@ def conv_ref(x, w, b, scale, shift, res, temb, act):
 
 
 def pack3(w):
-    out = torch.empty(w.numel(), device="cuda")
+    out = torch.empty(packed_floats(9, w.shape[0], w.shape[1]), device="cuda")
     call("ddpm_pack_conv3x3", P(w.cuda().contiguous()), w.shape[0], w.shape[1], 0, P(out), stream())
     return out
 
@@ -191,7 +191,8 @@ def test_conv1x1(case):
     x, w, b = rnd((B, ci, N, 1), 1), rnd((co, ci), 2, ci ** -0.5), rnd((co,), 3)
     out = torch.empty((B, N, 1, co), device="cuda")
     d = ConvDesc(batch=B, in_h=N, in_w=1, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=0, ldr=0, out_h=N, out_w=1)
-    bd, wd = b.cuda(), w.cuda()
+    bd, wd = b.cuda(), torch.empty(packed_floats(1, co, ci), device="cuda")
+    call("ddpm_pack_conv1x1", P(w.cuda()), co, ci, 0, P(wd), stream())
     ep = Epilogue(None, P(bd), None, None)
     call("ddpm_conv1x1_fwd", C.byref(d), P(to_nhwc(x)), None, P(wd), C.byref(ep), P(out), stream())
     assert_close(from_nhwc(out), F.conv2d(x, w[:, :, None, None], b), TOL, f"conv1x1 {case}")
@@ -205,7 +206,7 @@ def test_convT2x2_pad_crop(case):
     y = F.conv_transpose2d(x, w, b, stride=2)
     dy, dx = OH - y.shape[2], OW - y.shape[3]
     want = F.pad(y, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
-    wp = torch.empty(w.numel(), device="cuda")
+    wp = torch.empty(packed_floats(1, 4 * co, ci), device="cuda")
     call("ddpm_pack_convT2x2", P(w.cuda()), ci, co, P(wp), stream())
     out = torch.zeros((B, OH, OW, co), device="cuda")
     d = ConvDesc(batch=B, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=0, ldr=0, out_h=OH, out_w=OW,

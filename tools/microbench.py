@@ -15,7 +15,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from diffusion_model_amd._lib import ConvDesc, Epilogue, call  # noqa: E402
+from diffusion_model_amd._lib import ConvDesc, Epilogue, call, packed_floats  # noqa: E402
 
 
 def P(t):
@@ -48,7 +48,7 @@ def main():
         iters = a[5] if len(a) > 5 else 20
         x = torch.randn(B, H, W, ci, device=dev)
         w = torch.randn(co, ci, 3, 3, device=dev) * (9 * ci) ** -0.5
-        wp = torch.empty(w.numel(), device=dev)
+        wp = torch.empty(packed_floats(9, co, ci), device=dev)
         call("ddpm_pack_conv3x3", P(w), co, ci, 0, P(wp), S())
         y = torch.empty(B, H, W, co, device=dev)
         flops = 2.0 * B * H * W * co * ci * 9
