@@ -1,0 +1,360 @@
+// 3x3 convolution (padding 1) as implicit GEMM on split-bf16 MFMA with the activation tile resident
+// in LDS across the nine taps.
+//
+// A workgroup of 4 waves (2 x 2; two workgroups per CU, so that one's prologue, flush and epilogue
+// overlap the other's matrix work) owns a run of 32-pixel row groups of one 64-column tile and walks
+// it in tiles of up to 8 groups (256 consecutive pixels of the flattened (b, y, x) axis). For every
+// 16-channel chunk it stages the tile's pixels plus a halo ONCE -- fp32 from global memory, split into
+// three bf16 planes in registers, 112-byte LDS rows -- and the nine taps then read their operand
+// fragments from that one tile at a fixed row offset per tap.
+//
+// The LDS tile is indexed in PADDED pixel space: every sample is a grid of (H+1) x (W+1) positions
+// whose last row and last column are zeros, P(b, y, x) = b*(H+1)*(W+1) + y*(W+1) + x. A tap (dy, dx)
+// of any pixel is then the position P + dy*(W+1) + dx, and every out-of-image tap lands on a zero
+// position: no per-lane validity test, and consecutive lanes stay on consecutive LDS rows, which
+// keeps the 16-byte fragment reads conflict-free. The staging passes walk the padded positions; a
+// position that is no pixel loads with an out-of-range buffer offset, i.e. zeros.
+//
+// Weights never touch LDS: the packed buffer is fragment-major (one 1 KiB block per (tap, chunk,
+// 32-column block, plane)), so each wave loads exactly its own operand registers with coalesced
+// 16-byte loads, one step ahead of the MFMAs. A wave computes (4 row groups) x (one 32-column block)
+// = 4 accumulators, 24 MFMAs per step; the next chunk's activations are staged in passes of 64
+// positions, one pass per tap, into the other LDS buffer: one barrier per chunk.
+// Accuracy scheme as in conv_gemm.hip: six cross products, MFMA partial sums folded into a master
+// accumulator (round-to-nearest) after every chunk.
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace ddpm {
+namespace conv {
+namespace {
+
+#ifndef DDPM_HALO_ABLATE
+#define DDPM_HALO_ABLATE 0   // diagnostic builds only (wrong results): bit 0 no staging in the chunk loop, bit 1 no weight loads in the loop, bit 2 no LDS fragment reads in the loop, bit 3 no master fold, bit 4 no epilogue
+#endif
+constexpr int kThreads = 256;
+constexpr int kPassRows = kThreads / 4;    // padded positions staged per pass
+constexpr int NPASS = 6;                   // staging passes per chunk (<= 384 LDS rows)
+constexpr int kMaxLds = 160 * 1024 - 4096;
+constexpr int WM = 2, WN = 2;              // wave grid
+constexpr int BN = WN * 32;
+
+template <bool DUAL>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    __shared__ __attribute__((aligned(16))) int rowb[256];   // sample index of every tile row, -1 = no such pixel
+
+    const int W = p.in_w, H = p.in_h, HW = H * W;
+    const int PW = W + 1, PS = (H + 1) * PW;
+    const int HBUF = p.hrows * XROW;
+
+    const int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
+        id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+    }
+    const int n_tile = id % p.n_tiles;
+    const int m_block = id / p.n_tiles;
+    const int n0 = n_tile * BN;
+    const int g_begin = m_block * p.gpb;
+    const int g_end = min(p.groups_total, g_begin + p.gpb);
+    if (g_begin >= g_end) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int srow = tid >> 2, lq = tid & 3;   // staging: padded position (+ 64 per pass), 4-channel quad
+
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+    // byte offset of this lane's fragment piece in a (tap, chunk) slab, or OOB past the last column block
+    const int nb = (n0 >> 5) + wn;
+    const unsigned wcol = nb < p.nbp ? static_cast<unsigned>(nb) * 3072u + lane * 16u : OOB;
+    const unsigned chunk_stride_w = static_cast<unsigned>(p.nbp) * 3072u;
+    const unsigned tap_stride_w = chunk_stride_w * static_cast<unsigned>(p.kc16);
+
+    auto padded = [&](int m) {   // padded position of pixel m
+        const int b = m / HW;
+        const int rem = m - b * HW;
+        const int y = rem / W;
+        return b * PS + y * PW + (rem - y * W);
+    };
+
+    // Tiles of this run: as even as possible, at most p.tile_groups groups each. The second half of the
+    // grid (the workgroups that share CUs with the first half) starts with a half-size tile, so that the
+    // two workgroups of a CU are out of phase: one's prologue, fold and epilogue then overlap the
+    // other's MFMA steps instead of coinciding with them.
+    const int cnt = g_end - g_begin;
+    int first = 0;
+    if (blockIdx.x >= (nwg >> 1) && cnt > p.tile_groups) first = max(2, (min(cnt, p.tile_groups) / 2) & ~1);
+    const int rest = cnt - first;
+    const int ntile = (rest + p.tile_groups - 1) / p.tile_groups;
+    const int tq = rest / ntile, trem = rest - tq * ntile;
+
+    int g0 = g_begin;
+    for (int t = first ? -1 : 0; t < ntile; ++t) {
+        const int kg = t < 0 ? first : tq + (t < trem ? 1 : 0);
+        const int m0 = g0 * 32;
+        g0 += kg;
+        const int m_last = min(m0 + kg * 32, p.m_total) - 1;
+        const int P0 = padded(m0) - PW - 1;                   // padded position of LDS row 0 (may be negative)
+        const int nrows = padded(m_last) + PW + 1 - P0 + 1;   // <= p.hrows: the host sized the tiles for it
+
+        __syncthreads();   // the previous tile's epilogue reads rowb; its last chunk reads LDS
+        {
+            const int m = m0 + tid;
+            rowb[tid] = (tid < kg * 32 && m < p.m_total) ? m / HW : -1;
+        }
+
+        // LDS address of this lane's row in each of its (up to 4) row groups; rows that do not exist
+        // alias the tile's last pixel (their results are never stored)
+        int abase[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = min(m0 + (WM * i + wm) * 32 + r, m_last);
+            abase[i] = (padded(m) - P0) * XROW + h * 16;
+        }
+
+        const int pix0 = max(m0 - W - 1, 0);   // first pixel the tile can touch: base of the descriptors
+        const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.src1 + static_cast<long long>(pix0) * p.ld1, (p.src1_pixels - pix0) * p.ld1 * 4ll);
+        const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(p.src2 + static_cast<long long>(pix0) * p.ld2, (p.src2_pixels - pix0) * p.ld2 * 4ll);
+
+        // staging: pixel (relative to pix0) behind LDS row srow + 64*k, or -1 for a zero position
+        int srel[NPASS];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int L = srow + kPassRows * k;
+            const int pa = P0 + L;
+            int rel = -1;
+            if (L < nrows && pa >= 0) {
+                const int b = pa / PS;
+                const int rem = pa - b * PS;
+                const int y = rem / PW;
+                const int x = rem - y * PW;
+                if (y < H && x < W && b < p.batch) rel = (b * H + y) * W + x - pix0;
+            }
+            srel[k] = rel;
+        }
+        // (with two sources a chunk of 16 channels may straddle their boundary: both loads are issued,
+        // one of them out of range, and added at store time so that no wait follows the loads)
+        auto load_rel = [&](int rel, int kc, f32x4& second) -> f32x4 {
+            const bool ok = rel >= 0;
+            const int c = kc * XK + lq * 4;
+            if (DUAL) {
+                const unsigned o1 = (ok && c < p.c1) ? static_cast<unsigned>(rel) * p.ld1 * 4u + c * 4u : OOB;
+                const unsigned o2 = (ok && c >= p.c1 && c < p.ctot) ? static_cast<unsigned>(rel) * p.ld2 * 4u + (c - p.c1) * 4u : OOB;
+                second = buf_load(rs2, o2);
+                return buf_load(rs1, o1);
+            }
+            return buf_load(rs1, (ok && c < p.ctot) ? static_cast<unsigned>(rel) * p.ld1 * 4u + c * 4u : OOB);
+        };
+        auto load_pass = [&](int k, int kc, f32x4& second) -> f32x4 { return load_rel(srel[k], kc, second); };
+        auto store_pass = [&](const f32x4 v, int k, unsigned char* buf) {
+            const int L = srow + kPassRows * k;
+            if (L < p.hrows) split_store(v, buf + L * XROW + lq * 8);
+        };
+
+        // prologue: chunk 0 into buffer 0
+        {
+            constexpr int PG = DUAL ? 3 : NPASS;   // passes in flight together (register budget)
+#pragma unroll
+            for (int k0 = 0; k0 < NPASS; k0 += PG) {
+                f32x4 pre[PG], pre2[PG];
+#pragma unroll
+                for (int k = 0; k < PG; ++k) pre[k] = load_pass(k0 + k, 0, pre2[k]);
+#pragma unroll
+                for (int k = 0; k < PG; ++k) store_pass(DUAL ? pre[k] + pre2[k] : pre[k], k0 + k, hsm);
+            }
+        }
+
+        const int my_slots = (kg - wm + WM - 1) / WM;
+        f32x16 master[4];
+
+        auto k_loop = [&](auto slots_tag) {
+            constexpr int SL = decltype(slots_tag)::value;
+            constexpr int SLA = SL > 0 ? SL : 1;
+            f32x16 acc[SLA];
+#pragma unroll
+            for (int i = 0; i < SLA; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    acc[i][e] = 0.f;
+                    master[i][e] = 0.f;
+                }
+            // Weight fragments alternate between two register sets by tap parity; after tap 8 the first
+            // tap of the next chunk is parked in set 1 and moved to set 0 at the top of the chunk.
+            u32x4 bf[2][3];
+            auto load_b = [&](u32x4 (&dst)[3], int tap, int kc) {
+                const unsigned base = static_cast<unsigned>(tap) * tap_stride_w + static_cast<unsigned>(kc) * chunk_stride_w;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wcol, base + pl * 1024u, 0);
+            };
+            // Activation fragments: plane 2 of the NEXT tap is requested as soon as this tap's only
+            // term with plane 2 has issued, plane 1 after its last term, plane 0 at the top of the step
+            // (it is needed last): the reads of a step are covered by its own MFMAs.
+            bf16x8 a0[SLA], a1[SLA], a2[SLA];
+            auto read_plane = [&](bf16x8 (&dst)[SLA], int off, int pl) {
+#pragma unroll
+                for (int i = 0; i < SLA; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(hsm + (abase[i] + off) + pl * 32);
+            };
+            auto mma = [&](const bf16x8 (&a)[SLA], const u32x4& b) {
+#pragma unroll
+                for (int i = 0; i < SLA; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
+            };
+            if (SL > 0) load_b(bf[1], 0, 0);
+            __syncthreads();
+
+            for (int kc = 0; kc < p.kc16; ++kc) {
+                const int curoff = (kc & 1) * HBUF;
+                unsigned char* nxt = hsm + ((kc & 1) ^ 1) * HBUF;
+                const bool has_next = kc + 1 < p.kc16;
+                f32x4 areg = {0.f, 0.f, 0.f, 0.f}, areg2 = {0.f, 0.f, 0.f, 0.f};
+                if (SL > 0) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) bf[0][pl] = bf[1][pl];
+                    const int off0 = curoff - (PW + 1) * XROW;
+                    if (!(DDPM_HALO_ABLATE & 4)) {
+                        read_plane(a2, off0, 2);
+                        read_plane(a1, off0, 1);
+                    }
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int tapoff = curoff + ((tap / 3 - 1) * PW + (tap % 3 - 1)) * XROW;
+                    const int nextoff = curoff + (((tap + 1) / 3 - 1) * PW + ((tap + 1) % 3 - 1)) * XROW;
+                    if (SL > 0 && !(DDPM_HALO_ABLATE & 4)) read_plane(a0, tapoff, 0);
+                    // weights of the next step (after tap 8: the first tap of the next chunk)
+                    if (SL > 0 && !(DDPM_HALO_ABLATE & 2)) {
+                        if (tap < 8) load_b(bf[(tap + 1) & 1], tap + 1, kc);
+                        else if (has_next) load_b(bf[1], 0, kc + 1);
+                    }
+                    if (has_next && !(DDPM_HALO_ABLATE & 1)) {
+                        if (tap >= 1 && tap <= NPASS) store_pass(DUAL ? areg + areg2 : areg, tap - 1, nxt);
+                        if (tap < NPASS) areg = load_pass(tap, kc + 1, areg2);
+                    }
+                    if (SL > 0) {
+                        const u32x4 (&b)[3] = bf[tap & 1];
+                        mma(a2, b[0]);
+                        if (tap < 8 && !(DDPM_HALO_ABLATE & 4)) read_plane(a2, nextoff, 2);
+                        mma(a1, b[1]);
+                        mma(a1, b[0]);
+                        if (tap < 8 && !(DDPM_HALO_ABLATE & 4)) read_plane(a1, nextoff, 1);
+                        mma(a0, b[2]);
+                        mma(a0, b[1]);
+                        mma(a0, b[0]);
+                    }
+                }
+                if (SL > 0 && (!(DDPM_HALO_ABLATE & 8) || !has_next)) {
+#pragma unroll
+                    for (int i = 0; i < SLA; ++i) {
+                        master[i] += acc[i];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+                    }
+                }
+                __syncthreads();
+            }
+        };
+        using T0 = std::integral_constant<int, 0>;
+        using T1 = std::integral_constant<int, 1>;
+        using T2 = std::integral_constant<int, 2>;
+        using T3 = std::integral_constant<int, 3>;
+        using T4 = std::integral_constant<int, 4>;
+        if (my_slots == 4) k_loop(T4{});
+        else if (my_slots == 3) k_loop(T3{});
+        else if (my_slots == 2) k_loop(T2{});
+        else if (my_slots == 1) k_loop(T1{});
+        else k_loop(T0{});
+
+        // ---- epilogue (32-bit offsets from the tile's first pixel) ----------------------------
+        int n = n0 + wn * 32 + r;
+        int hq = 4 * h;
+        asm volatile("" : "+v"(n), "+v"(hq));   // keeps the 64 per-element offsets below from being hoisted out of the tile loop
+        if (n < p.n_total && (!(DDPM_HALO_ABLATE & 16) || p.act == 77)) {
+            const float sc = p.scale ? p.scale[n] : 1.0f;
+            const float sh = p.shift ? p.shift[n] : 0.0f;
+            float* out_t = p.out + static_cast<int64_t>(m0) * p.ldo;
+            const float* res_t = p.residual ? p.residual + static_cast<int64_t>(m0) * p.ldr : nullptr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i >= my_slots) continue;
+#pragma unroll
+                for (int eq = 0; eq < 4; ++eq) {
+                    const int row0 = (i * WM + wm) * 32 + 8 * eq + hq;   // rows row0 .. row0 + 3
+                    const int4 bs = *reinterpret_cast<const int4*>(&rowb[row0]);
+                    const int bb[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+                    for (int ei = 0; ei < 4; ++ei) {
+                        const int row = row0 + ei;
+                        const int b = bb[ei];
+                        float v = master[i][eq * 4 + ei] * sc + sh;
+                        if (res_t) v += b >= 0 ? res_t[static_cast<unsigned>(row * p.ldr + n)] : 0.f;
+                        v = apply_act_fast(v, p.act);
+                        if (p.temb) v += b >= 0 ? p.temb[static_cast<unsigned>(b * p.cout + n)] : 0.f;
+                        if (b >= 0) out_t[static_cast<unsigned>(row * p.ldo + n)] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool DUAL>
+int launch_one(const GemmParams& p, int grid, int lds, hipStream_t s) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<DUAL>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    if (attr != hipSuccess) {
+        set_error("conv3x3_halo_kernel: cannot reserve %d bytes of LDS: %s", kMaxLds, hipGetErrorString(attr));
+        return DDPM_E_LAUNCH;
+    }
+    conv3x3_halo_kernel<DUAL><<<dim3(grid), dim3(kThreads), lds, s>>>(p);
+    return check_launch("conv3x3_halo_kernel");
+}
+
+// LDS rows a tile of g groups can need: its pixels, the zero positions among them (one per image row,
+// W + 1 more per sample boundary) and W + 2 positions of halo on either side.
+int tile_rows(int g, int h, int w) {
+    const int px = g * 32;
+    return px + (px / w + 2) + ((px + 2 * w + 2) / (h * w) + 1) * (w + 1) + 2 * (w + 2);
+}
+
+}  // namespace
+
+int launch_conv3x3_halo(GemmParams& p, hipStream_t s) {
+    // shapes left to the generic kernel: very few columns, or images too wide for the LDS tile
+    if (p.n_total <= 32) return 1;
+    if (p.m_total != p.batch * p.in_h * p.in_w) return 1;
+    // two workgroups per CU: 2 buffers of hrows rows each within half of the LDS
+    const int max_rows = min(NPASS * kPassRows, (160 * 1024 / 2 - 1024 - 512) / (2 * XROW));
+    int tg = 0;
+    for (int g = 8; g >= 2; g -= 2)
+        if (tile_rows(g, p.in_h, p.in_w) <= max_rows) {
+            tg = g;
+            break;
+        }
+    if (tg == 0) return 1;
+    p.tile_groups = tg;
+    p.hrows = tile_rows(tg, p.in_h, p.in_w);
+    const int lds = 2 * p.hrows * XROW;
+    p.groups_total = (p.m_total + 31) / 32;
+    p.kc16 = (p.ctot + XK - 1) / XK;
+    p.nbp = (p.n_total + 31) / 32;
+    const long long wb = 3072ll * 9 * p.nbp * p.kc16;
+    if (wb >= 0x7fffffffll) return fail_invalid("weight tensor of 2 GiB or more");
+    p.w_bytes = static_cast<unsigned>(wb);
+    // one resident round of 512 workgroups, each covering 64 columns
+    p.n_tiles = (p.n_total + BN - 1) / BN;
+    int per_tile = 512 / p.n_tiles;
+    if (per_tile < 1) per_tile = 1;
+    p.gpb = (p.groups_total + per_tile - 1) / per_tile;
+    const int64_t grid = static_cast<int64_t>((p.groups_total + p.gpb - 1) / p.gpb) * p.n_tiles;
+    if (grid <= 0 || grid > 0x7fffffffll) return fail_invalid("conv grid size");
+    return p.c2 > 0 ? launch_one<true>(p, static_cast<int>(grid), lds, s) : launch_one<false>(p, static_cast<int>(grid), lds, s);
+}
+
+}  // namespace conv
+}  // namespace ddpm

@@ -28,66 +28,12 @@
 #include <cstring>
 #include <type_traits>
 
-#include "common.h"
+#include "conv_common.h"
 
 using ddpm::as_stream;
+using namespace ddpm::conv;
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int MODE_CONV3 = 0;        // 3x3, pad 1
-constexpr int MODE_CONV1 = 1;        // 1x1
-constexpr int MODE_CONVT = 2;        // 2x2 stride-2 transposed: GEMM + scatter
-constexpr int MODE_CONVT_DGRAD = 3;  // data gradient of MODE_CONVT: 4 taps gathered from the (out_h x out_w) image
-
-constexpr int BK = 32;
-constexpr int LDS_LD = 36;             // padded row length in floats
-constexpr int BM = 128;                // rows of a full tile (4 groups)
-constexpr unsigned OOB = 0x80000000u;  // any offset >= the descriptor's num_records reads as zero
-constexpr int kSlots = 512;            // resident workgroups: 256 CUs x 2 (LDS-limited)
-#ifndef DDPM_ABLATE
-#define DDPM_ABLATE 0                  // diagnostic builds only: 1 = no staging in the K loop, 2 = also no barrier, 3 = no MFMAs, 4 = loads but no LDS stores, 5 = LDS stores but no loads
-#endif
-
-struct GemmParams {
-    const float* src1;
-    const float* src2;
-    const float* w;
-    float* out;
-    const float* scale;
-    const float* shift;
-    const float* residual;
-    const float* temb;
-    int batch, in_h, in_w;
-    int win_y0, win_x0, win_h, win_w;
-    int c1, ld1, c2, ld2, ctot;
-    int n_total, cout;
-    int ldo, ldr, act;
-    int out_h, out_w, off_y, off_x;
-    int m_total, kc, taps;
-    int n_tiles, groups_total, gpb;
-    long long src1_pixels, src2_pixels;  // pixels (rows of ld floats) in each source tensor
-    unsigned w_bytes;
-    int kc16;                            // 16-channel chunks per tap (split-bf16 path)
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == DDPM_ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == DDPM_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    return v;
-}
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long long bytes) {
-    const unsigned n = bytes > 0x7fffffffll ? 0x7fffffffu : static_cast<unsigned>(bytes);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n, 0x00020000);
-}
-
-__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-}
 
 template <int BN, int MODE, bool DUAL>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
@@ -375,36 +321,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
 // LDS tile rows hold the three planes of one 16-deep slice (3 x 32 B) padded to 112 B, which makes the
 // 16-byte fragment reads (lane = row) conflict-free. Loads run two steps ahead of the MFMAs: the data
 // of step s+2 is requested during step s, split and written to LDS during step s+1.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int XK = 16;      // channels per K step
-constexpr int XROW = 112;   // LDS bytes per tile row
-constexpr int XFLUSH = 4;   // steps between folds into the master accumulator
-
-__device__ __forceinline__ void split_store(const f32x4 v, unsigned char* dst) {
-    unsigned u[4], m[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        u[e] = __float_as_uint(v[e]);
-        const float r1 = v[e] - __uint_as_float(u[e] & 0xffff0000u);
-        m[e] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(m[e] & 0xffff0000u);
-        l[e] = __float_as_uint(r2);
-    }
-    // upper halves of two dwords -> one dword of two bf16 (element 0 in the low half)
-    u32x2 hi, mid, lo;
-    hi[0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
-    hi[1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
-    mid[0] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
-    mid[1] = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
-    lo[0] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
-    lo[1] = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
-    *reinterpret_cast<u32x2*>(dst) = hi;
-    *reinterpret_cast<u32x2*>(dst + 32) = mid;
-    *reinterpret_cast<u32x2*>(dst + 64) = lo;
-}
-
 template <int BN, int MODE, bool DUAL>
 __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p) {
     constexpr int TN = BN / 64;               // 32-column MFMA tiles per wave (2 x 2 waves)
@@ -433,18 +349,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
     const int lrow = tid >> 2, lq = tid & 3;   // activation staging: row (and row + 64), 4-channel quad
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
-    // weight pieces of this thread: piece k of a row is plane k/2, half k%2 of the row's 96 bytes
+    // weight pieces of this thread: the tile's BN/32 row blocks are contiguous in the packed buffer,
+    // 192 pieces of 16 bytes each (plane, fragment lane); piece (plane, lane) of a block lands in LDS
+    // row lane & 31, plane, half lane >> 5
     unsigned wrow[NB];
     int wlds[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int idx = tid + 256 * i;
-        const int row = idx / 6, piece = idx - row * 6;
-        const int n = n0 + row;
-        wrow[i] = (row < BN && n < p.n_total) ? (static_cast<unsigned>(n) * p.kc16 * 96u + piece * 16u) : OOB;
-        wlds[i] = row < BN ? row * XROW + piece * 16 : -1;
+        const int blk = idx / 192, rem = idx - blk * 192;
+        const int plane = rem >> 6, fl = rem & 63;
+        const bool ok = blk < BN / 32 && (n0 >> 5) + blk < p.nbp;
+        wrow[i] = ok ? (static_cast<unsigned>((n0 >> 5) + blk) * 3072u + rem * 16u) : OOB;
+        wlds[i] = blk < BN / 32 ? (blk * 32 + (fl & 31)) * XROW + plane * 32 + (fl >> 5) * 16 : -1;
     }
-    const unsigned tap_stride_w = static_cast<unsigned>(p.n_total) * p.kc16 * 96u;
+    const unsigned chunk_stride_w = static_cast<unsigned>(p.nbp) * 3072u;            // one (tap, chunk)
+    const unsigned tap_stride_w = chunk_stride_w * static_cast<unsigned>(p.kc16);
     const int steps = p.taps * p.kc16;
 
     for (int g0 = g_begin; g0 < g_end; g0 += 4) {
@@ -522,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
                     areg[i] = buf_load(rs1, aoff1[i] + cb);
                 }
             }
-            const unsigned tb = static_cast<unsigned>(ltap) * tap_stride_w + static_cast<unsigned>(lkc) * 96u;
+            const unsigned tb = static_cast<unsigned>(ltap) * tap_stride_w + static_cast<unsigned>(lkc) * chunk_stride_w;
 #pragma unroll
             for (int i = 0; i < NB; ++i) breg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wrow[i] + tb, 0, 0);
             if (++lkc == p.kc16) {
@@ -678,7 +598,8 @@ int launch_gemm(GemmParams& p, hipStream_t s) {
     const bool x3 = split_math();
     p.groups_total = (p.m_total + 31) / 32;
     p.kc16 = (p.ctot + XK - 1) / XK;
-    const long long wb = x3 ? 96ll * p.taps * p.n_total * p.kc16 : 4ll * p.taps * p.n_total * p.ctot;
+    p.nbp = (p.n_total + 31) / 32;
+    const long long wb = x3 ? 3072ll * p.taps * p.nbp * p.kc16 : 4ll * p.taps * p.n_total * p.ctot;
     if (wb >= 0x7fffffffll) return ddpm::fail_invalid("weight tensor of 2 GiB or more");
     p.w_bytes = static_cast<unsigned>(wb);
     int best_bn = 0, best_gpb = 0;
@@ -819,36 +740,39 @@ __global__ void pack_convT_dgrad_kernel(const float* __restrict__ w, int cin, in
 
 
 // Split-bf16 packing: logical weight W(tap, n, c) = w[base + tap*st + (n / nq)*sq + (n % nq)*sn + c*sc]
-// -> out[tap][n][c / 16][plane][c % 16] (bf16, planes hi | mid | lo, channels padded with zeros to a
-// multiple of 16).
+// -> out[tap][c / 16][n / 32][plane][lane][8] (bf16; planes hi | mid | lo), lane = 32*h + n % 32 holding
+// channels 16*(c/16) + 8*h + 0..7: one (tap, chunk, row block, plane) is the 1 KiB MFMA operand
+// fragment of a wave. Rows are padded with zeros to a multiple of 32, channels to a multiple of 16.
 struct SplitPack {
     const float* w;
     unsigned short* out;
-    int taps, rows, cin, kc16, nq;
+    int taps, rows, cin, kc16, nbp, nq;
     long long base, st, sq, sn, sc;
 };
 
 __global__ void pack_split_kernel(const SplitPack a) {
-    const int64_t total = static_cast<int64_t>(a.taps) * a.rows * a.kc16 * 16;
+    const int64_t total = static_cast<int64_t>(a.taps) * a.kc16 * a.nbp * 512;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const int e = static_cast<int>(i & 15);
-        const int64_t chunk = i >> 4;                       // (tap*rows + n)*kc16 + kc
-        const int kc = static_cast<int>(chunk % a.kc16);
-        const int64_t tn = chunk / a.kc16;
-        const int n = static_cast<int>(tn % a.rows);
-        const int tap = static_cast<int>(tn / a.rows);
-        const int c = kc * 16 + e;
+        const int j = static_cast<int>(i & 7);
+        const int fl = static_cast<int>((i >> 3) & 63);
+        int64_t rest = i >> 9;                                 // (tap*kc16 + kc)*nbp + nb
+        const int nb = static_cast<int>(rest % a.nbp);
+        rest /= a.nbp;
+        const int kc = static_cast<int>(rest % a.kc16);
+        const int tap = static_cast<int>(rest / a.kc16);
+        const int n = nb * 32 + (fl & 31);
+        const int c = kc * 16 + (fl >> 5) * 8 + j;
         float v = 0.f;
-        if (c < a.cin) v = a.w[a.base + tap * a.st + (n / a.nq) * a.sq + (n % a.nq) * a.sn + c * a.sc];
+        if (c < a.cin && n < a.rows) v = a.w[a.base + tap * a.st + (n / a.nq) * a.sq + (n % a.nq) * a.sn + c * a.sc];
         const unsigned u = __float_as_uint(v);
         const float r1 = v - __uint_as_float(u & 0xffff0000u);
         const unsigned m = __float_as_uint(r1);
         const float r2 = r1 - __uint_as_float(m & 0xffff0000u);
-        unsigned short* o = a.out + chunk * 48 + e;
+        unsigned short* o = a.out + (i >> 9) * 1536 + fl * 8 + j;
         o[0] = static_cast<unsigned short>(u >> 16);
-        o[16] = static_cast<unsigned short>(m >> 16);
-        o[32] = static_cast<unsigned short>(__float_as_uint(r2) >> 16);
+        o[512] = static_cast<unsigned short>(m >> 16);
+        o[1024] = static_cast<unsigned short>(__float_as_uint(r2) >> 16);
     }
 }
 
@@ -861,13 +785,14 @@ int launch_split_pack(const float* w, float* out, int taps, int rows, int cin, i
     a.rows = rows;
     a.cin = cin;
     a.kc16 = (cin + 15) / 16;
+    a.nbp = (rows + 31) / 32;
     a.nq = nq;
     a.base = base;
     a.st = st;
     a.sq = sq;
     a.sn = sn;
     a.sc = sc;
-    const int64_t total = static_cast<int64_t>(taps) * rows * a.kc16 * 16;
+    const int64_t total = static_cast<int64_t>(taps) * a.kc16 * a.nbp * 512;
     const int grid = static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     pack_split_kernel<<<grid, 256, 0, s>>>(a);
     return ddpm::check_launch("pack_split_kernel");
@@ -888,7 +813,7 @@ __global__ void copy_transpose_kernel(const float* __restrict__ w, int rows, int
 extern "C" int64_t ddpm_packed_weight_floats(int taps, int rows, int cin) {
     if (taps <= 0 || rows <= 0 || cin <= 0) return 0;
     if (!split_math()) return static_cast<int64_t>(taps) * rows * cin;
-    return static_cast<int64_t>(taps) * rows * ((cin + 15) / 16) * 24;   // 96 bytes per 16-channel chunk
+    return static_cast<int64_t>(taps) * ((cin + 15) / 16) * ((rows + 31) / 32) * 768;   // 3 KiB per (tap, 16 channels, 32 rows)
 }
 
 extern "C" int ddpm_pack_conv1x1(const float* w, int rows, int cin, int transpose, float* out, void* stream) {
@@ -908,6 +833,10 @@ extern "C" int ddpm_conv3x3_fwd(const ddpm_conv_desc* d, const float* src1, cons
     GemmParams p;
     fill_common(p, d, src1, src2, w_packed, ep, out);
     p.taps = 9;
+    if (split_math()) {
+        const int rc = launch_conv3x3_halo(p, as_stream(stream));
+        if (rc <= 0) return rc;   // launched, or failed; positive = shape for the generic kernel
+    }
     return launch_gemm<MODE_CONV3>(p, as_stream(stream));
 }
 

@@ -9,6 +9,7 @@ Reference behaviour this schedule reproduces: first-iteration/unet.py:75-115,
 second-iteration/unet.py:118-158, third-iteration/unet.py:126-178.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -82,15 +83,12 @@ class UNetEngine(TrainMixin):
         self.prof = None       # when a list: (kernel label, flops, start event, end event) per MFMA launch
 
     def _gemm_label(self, kind, m, n):
-        """Name of the conv_gemm_kernel instance the library picks for an m x n problem (mirrors its cost rule)."""
-        groups = (m + 31) // 32
-        best = None
-        for bn in (128, 64):
-            per_tile = max(1, 512 // ((n + bn - 1) // bn))
-            cost = ((groups + per_tile - 1) // per_tile) * bn * (1.35 if bn == 64 else 1.0)
-            if best is None or cost < best[0]:
-                best = (cost, bn)
-        return f"conv_gemm<{best[1]},{kind}>"
+        """Name of the kernel family the library uses for a forward/data-gradient contraction (profiling label)."""
+        if os.environ.get("DDPM_CONV_MATH") == "fp32":
+            return f"conv_gemm_fp32<{kind}>"
+        if kind == "conv3x3" and n > 32:
+            return "conv3x3_halo<split-bf16>"
+        return f"conv_gemm_x3<{kind},split-bf16>"
 
     def _launch(self, label, flops, name, *args):
         if self.prof is None:

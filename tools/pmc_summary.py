@@ -15,13 +15,17 @@ def main(path):
     vcol = "value" if "value" in idx else [c for c in cols if "value" in c][0]
     agg = defaultdict(lambda: defaultdict(float))
     cnt = defaultdict(set)
+    dur = defaultdict(dict)
     for r in rows:
         agg[r[idx[namecol]]][r[idx[ccol]]] += float(r[idx[vcol]])
         if "dispatch_id" in idx:
             cnt[r[idx[namecol]]].add(r[idx["dispatch_id"]])
+            if "duration" in idx:
+                dur[r[idx[namecol]]][r[idx["dispatch_id"]]] = float(r[idx["duration"]])
     for k, d in agg.items():
         n = max(1, len(cnt[k]))
-        print(f"{k[:110]}  ({n} dispatches)")
+        avg_us = sum(dur[k].values()) / max(1, len(dur[k])) / 1e3
+        print(f"{k[:110]}  ({n} dispatches, {avg_us:.1f} us each under the profiler)")
         for c, v in sorted(d.items()):
             print(f"    {c:32s} {v/n:16.1f} per dispatch")
 
