@@ -29,7 +29,17 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3     # gfx950 dense fp32 matrix peak
+FP32_MFMA_PEAK_TFLOPS = 157.3     # gfx950 dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+BF16_MFMA_PEAK_TFLOPS = 2516.6    # gfx950 dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
+SPLIT_PRODUCTS = 6                # bf16 MFMA products per fp32 product in the split-bf16 kernels
+
+
+def kernel_peak(label):
+    """Matrix-core ceiling of a kernel family in algorithmic (fp32) TFLOP/s."""
+    if "split-bf16" in label:
+        return BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+    return FP32_MFMA_PEAK_TFLOPS
+
 T_FULL = 1000
 
 WORKLOADS = {
@@ -248,6 +258,7 @@ def main():
     achieved = dom[1][0] / dom[1][1] / 1e12
     prof_steps = args.steps if world == 1 else 2
     kernels = {k: dict(launches=v[2], avg_ms=round(v[1] / v[2] * 1e3, 4), tflops=round(v[0] / v[1] / 1e12, 2),
+                       peak_tflops=round(kernel_peak(k), 1), frac=round(v[0] / v[1] / 1e12 / kernel_peak(k), 4),
                        share_of_step=round(v[1] / prof_steps / sec_per_step, 3)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
     cfg = {"workload": wl["name"], "per_gpu_batch": B, "global_batch": total_b}
     if args.workload == "sample":
@@ -262,8 +273,11 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": cfg,
-        "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(kernel_peak(dom[0]), 1),
+                     "unit": "TFLOP/s", "frac": round(achieved / kernel_peak(dom[0]), 4), "traffic": None,
+                     "arithmetic": ("fp32 operands split exactly into 3 bf16 terms, 6 cross products per fp32 product on "
+                                    "v_mfma_f32_32x32x16_bf16 with fp32 accumulation: achieved/peak count algorithmic fp32 FLOP, "
+                                    "peak = bf16 dense peak / 6" if "split-bf16" in dom[0] else "v_mfma_f32_32x32x2_f32"),
                      "avg_launch_ms": round(dom[1][1] / dom[1][2] * 1e3, 4), "launches": dom[1][2],
                      "measured": "HIP events around every launch of the timed steps" if world == 1 else
                                  "HIP events in a 2-step pre-pass before the process group is created"},

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
             abase[i] = (padded(m) - P0) * XROW + h * 16;
         }
 
-        const int pix0 = max(m0 - W - 1, 0);   // first pixel the tile can touch: base of the descriptors
+        const int pix0 = __builtin_amdgcn_readfirstlane(max(m0 - W - 1, 0));   // first pixel the tile can touch: base of the descriptors
         const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.src1 + static_cast<long long>(pix0) * p.ld1, (p.src1_pixels - pix0) * p.ld1 * 4ll);
         const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(p.src2 + static_cast<long long>(pix0) * p.ld2, (p.src2_pixels - pix0) * p.ld2 * 4ll);
 
@@ -232,6 +232,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
                         if (tap < 8) load_b(bf[(tap + 1) & 1], tap + 1, kc);
                         else if (has_next) load_b(bf[1], 0, kc + 1);
                     }
+                    __builtin_amdgcn_sched_barrier(0);   // the weight loads stay here, a full step ahead of their use
                     if (has_next && !(DDPM_HALO_ABLATE & 1)) {
                         if (tap >= 1 && tap <= NPASS) store_pass(DUAL ? areg + areg2 : areg, tap - 1, nxt);
                         if (tap < NPASS) areg = load_pass(tap, kc + 1, areg2);
