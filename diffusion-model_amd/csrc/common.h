@@ -4,6 +4,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 #include "../../include/ddpm_mi355x.h"
 
@@ -31,6 +33,16 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 constexpr int kMaxGridX = 1 << 20;
+
+// DDPM_CONV_MATH=fp32 in the environment (read once) selects the plain fp32 MFMA kernels (and the
+// fp32 packed-weight format) instead of the split-bf16 ones: a diagnostic switch for A/B measurements.
+inline bool split_math() {
+    static const bool on = [] {
+        const char* e = getenv("DDPM_CONV_MATH");
+        return !(e && strcmp(e, "fp32") == 0);
+    }();
+    return on;
+}
 
 }  // namespace ddpm
 

@@ -580,15 +580,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
     }
 }
 
-// DDPM_CONV_MATH=fp32 in the environment (read once) selects the plain fp32 MFMA kernels and the
-// fp32 packed-weight format instead of the split-bf16 ones: a diagnostic switch for A/B measurements.
-bool split_math() {
-    static const bool on = [] {
-        const char* e = getenv("DDPM_CONV_MATH");
-        return !(e && strcmp(e, "fp32") == 0);
-    }();
-    return on;
-}
+using ddpm::split_math;
 
 template <int MODE>
 int launch_gemm(GemmParams& p, hipStream_t s) {
