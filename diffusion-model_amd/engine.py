@@ -319,7 +319,8 @@ class UNetEngine(TrainMixin):
             lse = torch.empty((b, h * w), device=x.buf.device, dtype=torch.float32)
             save.update(qkv=qkv, raw=raw, lse=lse)
         n = h * w
-        self._launch("attention_fwd", 2.0 * b * n * n * (dqp + c), "ddpm_attention_fwd", qkv.ptr, x.ptr, x.ld,
+        split = n >= 128 and c >= 64 and os.environ.get("DDPM_CONV_MATH") != "fp32"     # mirrors the library's choice
+        self._launch("attention_fwd<split-bf16>" if split else "attention_fwd<fp32>", 2.0 * b * n * n * (dqp + c), "ddpm_attention_fwd", qkv.ptr, x.ptr, x.ld,
                      _ptr(self.T(key + ".gamma")), out.ptr, out.ld, _ptr(raw), _ptr(lse), _ptr(temb), b, n, c, dqp, _stream())
 
     # ------------------------------------------------------------------ whole network, eval mode

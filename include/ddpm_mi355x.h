@@ -180,8 +180,10 @@ int ddpm_convT2x2_fwd(const ddpm_conv_desc* d, const float* src, const float* w_
  *   conv1x1: [rows][cin] (transpose=0) or its transpose [cin][rows] (transpose=1, the data-gradient
  *            GEMM of a 1x1 conv) -> taps 1.
  * Contents: every weight as an exact sum of three bf16 numbers (hi + mid + lo), laid out
- * [tap][row][cin/16][plane][16] with the channels zero-padded to a multiple of 16; with
- * DDPM_CONV_MATH=fp32 in the environment (diagnostic: plain fp32 MFMA kernels) fp32 [tap][row][cin]. */
+ * [tap][cin/16][rows/32][plane][lane = 32*h + row%32][8 channels 8h..8h+7] -- one (tap, 16-channel
+ * chunk, 32-row block, plane) is the 1 KiB MFMA operand fragment of a wave -- with rows zero-padded to
+ * a multiple of 32 and channels to a multiple of 16; with DDPM_CONV_MATH=fp32 in the environment
+ * (diagnostic: plain fp32 MFMA kernels) fp32 [tap][row][cin]. */
 int64_t ddpm_packed_weight_floats(int taps, int rows, int cin);
 int ddpm_pack_conv3x3(const float* w, int cout, int cin, int flip, float* out, void* stream);
 int ddpm_pack_convT2x2(const float* w, int cin, int cout, float* out, void* stream);
