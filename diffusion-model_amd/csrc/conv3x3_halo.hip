@@ -8,18 +8,18 @@
 // three bf16 planes in registers, 112-byte LDS rows -- and the nine taps then read their operand
 // fragments from that one tile at a fixed row offset per tap.
 //
-// The LDS tile is indexed in PADDED pixel space: every sample is a grid of (H+1) x (W+1) positions
-// whose last row and last column are zeros, P(b, y, x) = b*(H+1)*(W+1) + y*(W+1) + x. A tap (dy, dx)
-// of any pixel is then the position P + dy*(W+1) + dx, and every out-of-image tap lands on a zero
-// position: no per-lane validity test, and consecutive lanes stay on consecutive LDS rows, which
-// keeps the 16-byte fragment reads conflict-free. The staging passes walk the padded positions; a
-// position that is no pixel loads with an out-of-range buffer offset, i.e. zeros.
+// The LDS tile holds consecutive pixels of the flattened axis, W + 1 before and after the tile's own.
+// Tap (dy, dx) of the pixel in LDS row R is row R + dy*W + dx; a lane whose neighbour in that
+// direction does not exist (image border, other sample) reads from a small region of zeros instead,
+// at the same address modulo 256 bytes -- the banks its own row would have used -- so the 16-byte
+// fragment reads (consecutive lanes on consecutive 112-byte rows) stay conflict-free. Which
+// neighbours exist is four wave-level lane masks per row group, computed once per tile.
 //
 // Weights never touch LDS: the packed buffer is fragment-major (one 1 KiB block per (tap, chunk,
 // 32-column block, plane)), so each wave loads exactly its own operand registers with coalesced
 // 16-byte loads, one step ahead of the MFMAs. A wave computes (4 row groups) x (one 32-column block)
 // = 4 accumulators, 24 MFMAs per step; the next chunk's activations are staged in passes of 64
-// positions, one pass per tap, into the other LDS buffer: one barrier per chunk.
+// rows, one pass per tap, into the other LDS buffer: one barrier per chunk.
 // Accuracy scheme as in conv_gemm.hip: six cross products, MFMA partial sums folded into a master
 // accumulator (round-to-nearest) after every chunk.
 #include <type_traits>
@@ -34,7 +34,7 @@ namespace {
 #define DDPM_HALO_ABLATE 0   // diagnostic builds only (wrong results): bit 0 no staging in the chunk loop, bit 1 no weight loads in the loop, bit 2 no LDS fragment reads in the loop, bit 3 no master fold, bit 4 no epilogue
 #endif
 constexpr int kThreads = 256;
-constexpr int kPassRows = kThreads / 4;    // padded positions staged per pass
+constexpr int kPassRows = kThreads / 4;    // LDS rows staged per pass
 constexpr int NPASS = 6;                   // staging passes per chunk (<= 384 LDS rows)
 constexpr int kMaxLds = 160 * 1024 - 4096;
 constexpr int WM = 2, WN = 2;              // wave grid
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
     __shared__ __attribute__((aligned(16))) int rowb[256];   // sample index of every tile row, -1 = no such pixel
 
     const int W = p.in_w, H = p.in_h, HW = H * W;
-    const int PW = W + 1, PS = (H + 1) * PW;
     const int HBUF = p.hrows * XROW;
+    const int ZOFF = (2 * HBUF + 255) & ~255;   // 384 bytes of zeros behind the two buffers, 256-byte aligned
 
     const int nwg = gridDim.x;
     int id = blockIdx.x;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
-    const int srow = tid >> 2, lq = tid & 3;   // staging: padded position (+ 64 per pass), 4-channel quad
+    const int srow = tid >> 2, lq = tid & 3;   // staging: LDS row (+ 64 per pass), 4-channel quad
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
     // byte offset of this lane's fragment piece in a (tap, chunk) slab, or OOB past the last column block
@@ -76,12 +76,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
     const unsigned chunk_stride_w = static_cast<unsigned>(p.nbp) * 3072u;
     const unsigned tap_stride_w = chunk_stride_w * static_cast<unsigned>(p.kc16);
 
-    auto padded = [&](int m) {   // padded position of pixel m
-        const int b = m / HW;
-        const int rem = m - b * HW;
-        const int y = rem / W;
-        return b * PS + y * PW + (rem - y * W);
-    };
+    if (tid < 96) reinterpret_cast<unsigned*>(hsm + ZOFF)[tid] = 0u;
 
     // Tiles of this run: as even as possible, at most p.tile_groups groups each. The second half of the
     // grid (the workgroups that share CUs with the first half) starts with a half-size tile, so that the
@@ -99,9 +94,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
         const int kg = t < 0 ? first : tq + (t < trem ? 1 : 0);
         const int m0 = g0 * 32;
         g0 += kg;
-        const int m_last = min(m0 + kg * 32, p.m_total) - 1;
-        const int P0 = padded(m0) - PW - 1;                   // padded position of LDS row 0 (may be negative)
-        const int nrows = padded(m_last) + PW + 1 - P0 + 1;   // <= p.hrows: the host sized the tiles for it
+        const int hr = kg * 32 + 2 * W + 2;   // LDS rows in use: the tile's pixels and W + 1 on either side
+        const int hp0 = m0 - W - 1;           // pixel behind LDS row 0 (may be negative)
 
         __syncthreads();   // the previous tile's epilogue reads rowb; its last chunk reads LDS
         {
@@ -109,35 +103,29 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
             rowb[tid] = (tid < kg * 32 && m < p.m_total) ? m / HW : -1;
         }
 
-        // LDS address of this lane's row in each of its (up to 4) row groups; rows that do not exist
-        // alias the tile's last pixel (their results are never stored)
+        // This lane's row in each of its (up to 4) row groups: LDS address, and which neighbours exist.
+        // The four conditions are wave-level lane masks (SGPR pairs) that the tap selects combine.
         int abase[4];
+        bool up[4], down[4], left[4], right[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = min(m0 + (WM * i + wm) * 32 + r, m_last);
-            abase[i] = (padded(m) - P0) * XROW + h * 16;
+            const int row = (WM * i + wm) * 32 + r;
+            const int m = m0 + row;
+            const int yy = m / W;
+            const int x = m - yy * W;
+            const int y = yy % H;
+            up[i] = y > 0;
+            down[i] = y < H - 1;
+            left[i] = x > 0;
+            right[i] = x < W - 1;
+            abase[i] = (row + W + 1) * XROW + h * 16;
         }
 
-        const int pix0 = __builtin_amdgcn_readfirstlane(max(m0 - W - 1, 0));   // first pixel the tile can touch: base of the descriptors
+        const int pix0 = __builtin_amdgcn_readfirstlane(max(hp0, 0));   // first pixel the tile can touch: base of the descriptors
         const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.src1 + static_cast<long long>(pix0) * p.ld1, (p.src1_pixels - pix0) * p.ld1 * 4ll);
         const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(p.src2 + static_cast<long long>(pix0) * p.ld2, (p.src2_pixels - pix0) * p.ld2 * 4ll);
+        const int shift0 = hp0 - pix0;   // <= 0: LDS row L holds descriptor pixel L + shift0
 
-        // staging: pixel (relative to pix0) behind LDS row srow + 64*k, or -1 for a zero position
-        int srel[NPASS];
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) {
-            const int L = srow + kPassRows * k;
-            const int pa = P0 + L;
-            int rel = -1;
-            if (L < nrows && pa >= 0) {
-                const int b = pa / PS;
-                const int rem = pa - b * PS;
-                const int y = rem / PW;
-                const int x = rem - y * PW;
-                if (y < H && x < W && b < p.batch) rel = (b * H + y) * W + x - pix0;
-            }
-            srel[k] = rel;
-        }
         // (with two sources a chunk of 16 channels may straddle their boundary: both loads are issued,
         // one of them out of range, and added at store time so that no wait follows the loads)
         auto load_rel = [&](int rel, int kc, f32x4& second) -> f32x4 {
@@ -151,7 +139,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
             }
             return buf_load(rs1, (ok && c < p.ctot) ? static_cast<unsigned>(rel) * p.ld1 * 4u + c * 4u : OOB);
         };
-        auto load_pass = [&](int k, int kc, f32x4& second) -> f32x4 { return load_rel(srel[k], kc, second); };
+        // staging pass k: LDS row srow + 64*k; rows past the tile and pixels before the tensor load zeros
+        // (pixels past its end are cut off by the descriptor)
+        auto load_pass = [&](int k, int kc, f32x4& second) -> f32x4 {
+            const int L = srow + kPassRows * k;
+            return load_rel(L < hr ? L + shift0 : -1, kc, second);
+        };
         auto store_pass = [&](const f32x4 v, int k, unsigned char* buf) {
             const int L = srow + kPassRows * k;
             if (L < p.hrows) split_store(v, buf + L * XROW + lq * 8);
@@ -196,9 +189,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
             // term with plane 2 has issued, plane 1 after its last term, plane 0 at the top of the step
             // (it is needed last): the reads of a step are covered by its own MFMAs.
             bf16x8 a0[SLA], a1[SLA], a2[SLA];
-            auto read_plane = [&](bf16x8 (&dst)[SLA], int off, int pl) {
+            // Fragment of tap (dy, dx) for row group i: the row at the tap's offset, or -- for a lane whose
+            // neighbour in that direction does not exist -- the zero region at the same offset modulo 256,
+            // i.e. on the banks the row itself would have used: the read stays conflict-free.
+            auto read_plane = [&](bf16x8 (&dst)[SLA], int curoff, int tap, int pl) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const int off = curoff + (dy * W + dx) * XROW;
 #pragma unroll
-                for (int i = 0; i < SLA; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(hsm + (abase[i] + off) + pl * 32);
+                for (int i = 0; i < SLA; ++i) {
+                    const int nat = abase[i] + off;
+                    bool ok = true;
+                    if (dy < 0) ok = ok && up[i];
+                    if (dy > 0) ok = ok && down[i];
+                    if (dx < 0) ok = ok && left[i];
+                    if (dx > 0) ok = ok && right[i];
+                    const int addr = (dy == 0 && dx == 0) ? nat : (ok ? nat : (ZOFF | (nat & 255)));
+                    dst[i] = *reinterpret_cast<const bf16x8*>(hsm + addr + pl * 32);
+                }
             };
             auto mma = [&](const bf16x8 (&a)[SLA], const u32x4& b) {
 #pragma unroll
@@ -216,17 +223,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
                 if (SL > 0) {
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) bf[0][pl] = bf[1][pl];
-                    const int off0 = curoff - (PW + 1) * XROW;
                     if (!(DDPM_HALO_ABLATE & 4)) {
-                        read_plane(a2, off0, 2);
-                        read_plane(a1, off0, 1);
+                        read_plane(a2, curoff, 0, 2);
+                        read_plane(a1, curoff, 0, 1);
                     }
                 }
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    const int tapoff = curoff + ((tap / 3 - 1) * PW + (tap % 3 - 1)) * XROW;
-                    const int nextoff = curoff + (((tap + 1) / 3 - 1) * PW + ((tap + 1) % 3 - 1)) * XROW;
-                    if (SL > 0 && !(DDPM_HALO_ABLATE & 4)) read_plane(a0, tapoff, 0);
+                    if (SL > 0 && !(DDPM_HALO_ABLATE & 4)) read_plane(a0, curoff, tap, 0);
                     // weights of the next step (after tap 8: the first tap of the next chunk)
                     if (SL > 0 && !(DDPM_HALO_ABLATE & 2)) {
                         if (tap < 8) load_b(bf[(tap + 1) & 1], tap + 1, kc);
@@ -240,10 +244,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
                     if (SL > 0) {
                         const u32x4 (&b)[3] = bf[tap & 1];
                         mma(a2, b[0]);
-                        if (tap < 8 && !(DDPM_HALO_ABLATE & 4)) read_plane(a2, nextoff, 2);
+                        if (tap < 8 && !(DDPM_HALO_ABLATE & 4)) read_plane(a2, curoff, tap + 1, 2);
                         mma(a1, b[1]);
                         mma(a1, b[0]);
-                        if (tap < 8 && !(DDPM_HALO_ABLATE & 4)) read_plane(a1, nextoff, 1);
+                        if (tap < 8 && !(DDPM_HALO_ABLATE & 4)) read_plane(a1, curoff, tap + 1, 1);
                         mma(a0, b[2]);
                         mma(a0, b[1]);
                         mma(a0, b[0]);
@@ -316,12 +320,8 @@ int launch_one(const GemmParams& p, int grid, int lds, hipStream_t s) {
     return check_launch("conv3x3_halo_kernel");
 }
 
-// LDS rows a tile of g groups can need: its pixels, the zero positions among them (one per image row,
-// W + 1 more per sample boundary) and W + 2 positions of halo on either side.
-int tile_rows(int g, int h, int w) {
-    const int px = g * 32;
-    return px + (px / w + 2) + ((px + 2 * w + 2) / (h * w) + 1) * (w + 1) + 2 * (w + 2);
-}
+// LDS rows of a tile of g groups: its pixels and W + 1 pixels of halo on either side.
+int tile_rows(int g, int w) { return g * 32 + 2 * w + 2; }
 
 }  // namespace
 
@@ -329,18 +329,18 @@ int launch_conv3x3_halo(GemmParams& p, hipStream_t s) {
     // shapes left to the generic kernel: very few columns, or images too wide for the LDS tile
     if (p.n_total <= 32) return 1;
     if (p.m_total != p.batch * p.in_h * p.in_w) return 1;
-    // two workgroups per CU: 2 buffers of hrows rows each within half of the LDS
-    const int max_rows = min(NPASS * kPassRows, (160 * 1024 / 2 - 1024 - 512) / (2 * XROW));
+    // two workgroups per CU: 2 buffers of hrows rows each and the zero region within half of the LDS
+    const int max_rows = min(NPASS * kPassRows, (160 * 1024 / 2 - 1024 - 256 - 384 - 512) / (2 * XROW));
     int tg = 0;
     for (int g = 8; g >= 2; g -= 2)
-        if (tile_rows(g, p.in_h, p.in_w) <= max_rows) {
+        if (tile_rows(g, p.in_w) <= max_rows) {
             tg = g;
             break;
         }
     if (tg == 0) return 1;
     p.tile_groups = tg;
-    p.hrows = tile_rows(tg, p.in_h, p.in_w);
-    const int lds = 2 * p.hrows * XROW;
+    p.hrows = tile_rows(tg, p.in_w);
+    const int lds = ((2 * p.hrows * XROW + 255) & ~255) + 384;
     p.groups_total = (p.m_total + 31) / 32;
     p.kc16 = (p.ctot + XK - 1) / XK;
     p.nbp = (p.n_total + 31) / 32;
