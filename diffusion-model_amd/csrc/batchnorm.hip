@@ -63,21 +63,24 @@ __device__ __forceinline__ void block_reduce8(double v[8], const Lanes& l, doubl
 }
 
 
-// Deterministic finishing sum: a 256-thread workgroup finishes 16 consecutive outputs; thread
-// (li = tid & 15, sl = tid >> 4) adds every 16th partial, the 16 slices are then added in order.
-// Returns the total in the threads with sl == 0.
+// Deterministic finishing sum: a 256-thread workgroup finishes kFin consecutive outputs; thread
+// (li = tid % kFin, sl = tid / kFin) adds every kSlices-th partial, the slices are then added in
+// order. Few outputs per workgroup and many slices: the kernel is a chain of dependent loads, so its
+// time is the number of partials per slice. Returns the total in the threads with sl == 0.
+constexpr int kFin = 4;
+constexpr int kSlices = kThreads / kFin;
 __device__ __forceinline__ double sliced_sum(const double* __restrict__ partial, int nblk, int64_t stride, int64_t offset, bool valid,
                                              double* sh /* [256] */) {
-    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int li = threadIdx.x % kFin, sl = threadIdx.x / kFin;
     double acc = 0.0;
     if (valid)
-        for (int b = sl; b < nblk; b += 16) acc += partial[static_cast<int64_t>(b) * stride + offset];
+        for (int b = sl; b < nblk; b += kSlices) acc += partial[static_cast<int64_t>(b) * stride + offset];
     __syncthreads();
-    sh[sl * 16 + li] = acc;
+    sh[sl * kFin + li] = acc;
     __syncthreads();
     double tot = 0.0;
     if (sl == 0)
-        for (int k = 0; k < 16; ++k) tot += sh[k * 16 + li];
+        for (int k = 0; k < kSlices; ++k) tot += sh[k * kFin + li];
     return tot;
 }
 
@@ -111,11 +114,11 @@ __global__ __launch_bounds__(kThreads) void bn_stats_final_kernel(const double* 
                                                                    float* __restrict__ invstd, float* __restrict__ running_mean,
                                                                    float* __restrict__ running_var) {
     __shared__ double sh[kThreads];
-    const int ch = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int ch = blockIdx.x * kFin + (threadIdx.x % kFin);
     const bool valid = ch < c;
     const double s = sliced_sum(partial, nblk, 2 * static_cast<int64_t>(c), ch, valid, sh);
     const double ss = sliced_sum(partial, nblk, 2 * static_cast<int64_t>(c), c + ch, valid, sh);
-    if ((threadIdx.x >> 4) != 0 || !valid) return;
+    if (threadIdx.x / kFin != 0 || !valid) return;
     const double m = s / static_cast<double>(rows);
     double var = ss / static_cast<double>(rows) - m * m;
     if (var < 0.0) var = 0.0;
@@ -210,11 +213,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_final_kernel(const double* __
                                                                  float* __restrict__ dw, float* __restrict__ db,
                                                                  float* __restrict__ sums) {
     __shared__ double sh[kThreads];
-    const int ch = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int ch = blockIdx.x * kFin + (threadIdx.x % kFin);
     const bool valid = ch < c;
     const double s = sliced_sum(partial, nblk, 2 * static_cast<int64_t>(c), ch, valid, sh);
     const double sx = sliced_sum(partial, nblk, 2 * static_cast<int64_t>(c), c + ch, valid, sh);
-    if ((threadIdx.x >> 4) != 0 || !valid) return;
+    if (threadIdx.x / kFin != 0 || !valid) return;
     sums[ch] = static_cast<float>(s);
     sums[c + ch] = static_cast<float>(sx);
     if (accumulate) {
@@ -301,15 +304,15 @@ __global__ __launch_bounds__(kThreads) void colsum_partial_kernel(const float* _
     }
 }
 
-// grid (ceil(c/16), groups)
+// grid (ceil(c/kFin), groups)
 __global__ __launch_bounds__(kThreads) void colsum_final_kernel(const double* __restrict__ partial, int groups, int chunks, int c,
                                                                  int accumulate, float* __restrict__ out) {
     __shared__ double sh[kThreads];
-    const int ch = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int ch = blockIdx.x * kFin + (threadIdx.x % kFin);
     const int64_t g = blockIdx.y;
     const bool valid = ch < c;
     const double s = sliced_sum(partial + g * chunks * c, chunks, c, ch, valid, sh);
-    if ((threadIdx.x >> 4) != 0 || !valid) return;
+    if (threadIdx.x / kFin != 0 || !valid) return;
     const int64_t idx = g * c + ch;
     out[idx] = accumulate ? out[idx] + static_cast<float>(s) : static_cast<float>(s);
 }
@@ -333,7 +336,7 @@ extern "C" int ddpm_bn_stats(const float* x, int ldx, int64_t rows, int c, float
     DDPM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
     const int nb = partial_blocks(rows, c);
     bn_stats_partial_kernel<<<nb, kThreads, 0, as_stream(stream)>>>(x, ldx, rows, c, workspace);
-    bn_stats_final_kernel<<<(c + 15) / 16, kThreads, 0, as_stream(stream)>>>(workspace, nb, rows, c, eps, momentum, mean,
+    bn_stats_final_kernel<<<(c + kFin - 1) / kFin, kThreads, 0, as_stream(stream)>>>(workspace, nb, rows, c, eps, momentum, mean,
                                                                                              invstd, running_mean, running_var);
     return ddpm::check_launch("bn_stats");
 }
@@ -370,10 +373,10 @@ extern "C" int ddpm_bn_bwd(const float* x, int ldx, const float* dout, int ldd, 
     hipStream_t s = as_stream(stream);
     const int nb = partial_blocks(rows, c);
     bn_bwd_partial_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, act, rows, c, workspace);
-    bn_bwd_final_kernel<<<(c + 15) / 16, kThreads, 0, s>>>(workspace, nb, c, accumulate, dw, db, sums);
+    bn_bwd_final_kernel<<<(c + kFin - 1) / kFin, kThreads, 0, s>>>(workspace, nb, c, accumulate, dw, db, sums);
     bn_bwd_apply_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, sums, act, rows, c, dx, lddx,
                                                 dresidual, lddr, dconv_bias ? workspace : nullptr);
-    if (dconv_bias) colsum_final_kernel<<<dim3((c + 15) / 16, 1), kThreads, 0, s>>>(workspace, 1, nb, c, accumulate, dconv_bias);
+    if (dconv_bias) colsum_final_kernel<<<dim3((c + kFin - 1) / kFin, 1), kThreads, 0, s>>>(workspace, 1, nb, c, accumulate, dconv_bias);
     return ddpm::check_launch("bn_bwd");
 }
 
@@ -386,6 +389,6 @@ extern "C" int ddpm_colsum(const float* x, int ld, int groups, int64_t rows_per_
     if (chunks > kMaxColsumBlocks / groups) chunks = kMaxColsumBlocks / groups;
     hipStream_t s = as_stream(stream);
     colsum_partial_kernel<<<groups * chunks, kThreads, 0, s>>>(x, ld, rows_per_group, c, chunks, workspace);
-    colsum_final_kernel<<<dim3((c + 15) / 16, groups), kThreads, 0, s>>>(workspace, groups, chunks, c, accumulate, out);
+    colsum_final_kernel<<<dim3((c + kFin - 1) / kFin, groups), kThreads, 0, s>>>(workspace, groups, chunks, c, accumulate, out);
     return ddpm::check_launch("colsum");
 }
