@@ -80,7 +80,9 @@ class UNetEngine(TrainMixin):
         self.num_classes = num_classes
         self._cache = {}
         self._tensors = None
-        self.prof = None       # when a list: (kernel label, flops, start event, end event) per MFMA launch
+        self.prof = None       # when a list: (kernel label, flops, start event, end event) per sampled MFMA launch
+        self.prof_stride = 1   # every prof_stride-th MFMA launch is bracketed by events (a stride that does not
+        self._prof_i = 0       # divide the launches per step walks through all launch sites over the steps)
 
     def _gemm_label(self, kind, m, n):
         """Name of the kernel family the library uses for a forward/data-gradient contraction (profiling label)."""
@@ -92,6 +94,9 @@ class UNetEngine(TrainMixin):
 
     def _launch(self, label, flops, name, *args):
         if self.prof is None:
+            return call(name, *args)
+        self._prof_i += 1
+        if self._prof_i % self.prof_stride:
             return call(name, *args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
