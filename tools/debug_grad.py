@@ -1,0 +1,26 @@
+import sys, os, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from oracle import ddpm_oracle as O
+from seeding import seeded_ints, seeded_state_dict, seeded_tensor
+import diffusion_model_amd as pkg
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+hw = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+U = pkg.make_unet_class(2)
+m = U(3, 3, 64, 128)
+m.load_state_dict(seeded_state_dict(m.state_dict(), 12))
+m = m.cuda().train()
+sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+x, tgt = seeded_tensor((B, 3, hw, hw), 3, "x"), seeded_tensor((B, 3, hw, hw), 4, "tgt")
+t = seeded_ints((B,), 1000, 5, "t")
+out = m(x.cuda(), t.cuda())
+loss = torch.nn.MSELoss()(out, tgt.cuda())
+loss.backward()
+ref_loss, grads, ref_out, _ = O.loss_and_grads(sd, 2, x, t, tgt)
+print("loss", loss.item(), ref_loss.item(), "out err", (out.detach().cpu() - ref_out).abs().max().item())
+for k, p in m.named_parameters():
+    ref = grads[k]
+    err = (p.grad.cpu() - ref).abs().max().item()
+    ratio = err / (2e-3 * ref.abs().max().item() + 5e-6)
+    if ratio > float(os.environ.get("RATIO", "0.2")):
+        print(f"{ratio:8.2f} {k:60s} err {err:.3e} max {ref.abs().max().item():.3e}")
