@@ -200,6 +200,220 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
+
+// ---- split-bf16 variant (128 x 128 tiles) -------------------------------------------------------
+// Same decomposition, on v_mfma_f32_32x32x16_bf16: both operands are split into three bf16 planes
+// (x = hi + mid + lo exactly) on their way from global memory to LDS and a product is the sum of its
+// six cross terms of weight >= 2^-16, accumulated in fp32 (dropped terms below 2^-23 of the product).
+// The LDS image keeps the natural [pixel][channel] order; the MFMA wants 8 consecutive PIXELS of one
+// channel per lane, which the transposing read ds_read_b64_tr_b16 delivers (4 pixel rows x 16
+// channels per 16-lane group; rows of 256 + 64 bytes keep the four rows of a 32-lane half on
+// different banks). The MFMA accumulator is folded into a master accumulator with a round-to-nearest
+// add every 8 steps (128 pixels), because the bf16 MFMA truncates when it accumulates.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int XKP = 16;                  // pixels per K-step
+constexpr int XROWB = 128 * 2 + 64;      // bytes of one pixel row of one plane
+constexpr int XPLANE = XKP * XROWB;
+constexpr int XFOLD = 8;
+
+__device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst) {
+    unsigned u[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        u[e] = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(u[e] & 0xffff0000u);
+        m[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(m[e] & 0xffff0000u);
+        l[e] = __float_as_uint(r2);
+    }
+    u32x2 hi, mid, lo;
+    hi[0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
+    hi[1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
+    mid[0] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
+    mid[1] = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
+    lo[0] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
+    lo[1] = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
+    *reinterpret_cast<u32x2*>(dst) = hi;
+    *reinterpret_cast<u32x2*>(dst + XPLANE) = mid;
+    *reinterpret_cast<u32x2*>(dst + 2 * XPLANE) = lo;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams p) {
+    constexpr int BT = 128;
+    constexpr int F4R = BT / 4;           // float4 per tile row
+    constexpr int LPT = XKP * F4R / 256;  // float4 loads per thread per operand (2)
+    constexpr int RSTEP = 256 / F4R;      // rows between a thread's consecutive loads (8)
+    __shared__ __attribute__((aligned(16))) unsigned char sA[2][3 * XPLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char sB[2][3 * XPLANE];
+
+    int id = blockIdx.x;
+    const int nt = id % p.n_tiles; id /= p.n_tiles;
+    const int mt = id % p.m_tiles; id /= p.m_tiles;
+    const int tap = id % p.taps;
+    const int split = id / p.taps;
+    const int m0 = mt * BT, n0 = nt * BT;
+    const int k_begin = split * p.k_chunk;
+    const int k_end = min(p.k_total, k_begin + p.k_chunk);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    int dy = 0, dx = 0;
+    if (MODE == WG_CONV3) {
+        dy = tap / 3 - 1;
+        dx = tap % 3 - 1;
+    }
+    const int per = p.h * p.w;
+
+    const long long pixels = static_cast<long long>(p.batch) * per;
+    long long base_pix = static_cast<long long>(k_begin) - p.w - 1;
+    if (base_pix < 0) base_pix = 0;
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.b + base_pix * p.ldb, (pixels - base_pix) * p.ldb * 4ll);
+    const long long a_pixels = static_cast<long long>(p.batch) * p.a_h * p.a_w;
+    const long long a_base = MODE == WG_CONVT ? 0 : base_pix;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a + a_base * p.lda, (a_pixels - a_base) * p.lda * 4ll);
+    const int base_i = static_cast<int>(base_pix);
+
+    const int row0 = tid / F4R, c4 = tid % F4R;
+    const unsigned ca = m0 + c4 * 4 < p.m_total ? static_cast<unsigned>(m0 + c4 * 4) * 4u : OOB;
+    const unsigned cb = n0 + c4 * 4 < p.n_total ? static_cast<unsigned>(n0 + c4 * 4) * 4u : OOB;
+    const unsigned inv_w = static_cast<unsigned>((0x100000000ull + p.w - 1) / p.w);
+    int rb[LPT], rrem[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int pk = k_begin + row0 + RSTEP * i;
+        rb[i] = pk / per;
+        rrem[i] = pk - rb[i] * per;
+    }
+
+    f32x16 acc[2][2], master[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                master[i][j][e] = 0.f;
+            }
+
+    f32x4 areg[LPT], breg[LPT];
+    auto load_global = [&](int k0) {   // must be called with k0 = k_begin, k_begin + XKP, ... in order
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int pk = k0 + row0 + RSTEP * i;
+            const int rem = rrem[i], bi = rb[i];
+            const int y = p.w == 1 ? rem : static_cast<int>(__umulhi(static_cast<unsigned>(rem), inv_w));
+            const int x = rem - y * p.w;
+            const bool in_chunk = pk < k_end;
+            unsigned oa, ob;
+            if (MODE == WG_CONVT) {
+                const int oy = 2 * y + (tap >> 1) + p.off_y, ox = 2 * x + (tap & 1) + p.off_x;
+                const bool ok = in_chunk && oy >= 0 && oy < p.a_h && ox >= 0 && ox < p.a_w;
+                oa = ok ? static_cast<unsigned>((bi * p.a_h + oy) * p.a_w + ox) * p.lda * 4u + ca : OOB;
+                ob = in_chunk ? static_cast<unsigned>(pk - base_i) * p.ldb * 4u + cb : OOB;
+            } else {
+                oa = in_chunk ? static_cast<unsigned>(pk - base_i) * p.lda * 4u + ca : OOB;
+                const int yy = y + dy, xx = x + dx;
+                const bool ok = in_chunk && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
+                ob = ok ? static_cast<unsigned>(pk - base_i + dy * p.w + dx) * p.ldb * 4u + cb : OOB;
+            }
+            areg[i] = buf_load(rs_a, oa);
+            breg[i] = buf_load(rs_b, ob);
+            int nr = rem + XKP;
+            int nb = bi;
+            while (nr >= per) {
+                nr -= per;
+                ++nb;
+            }
+            rrem[i] = nr;
+            rb[i] = nb;
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int off = (row0 + RSTEP * i) * XROWB + c4 * 8;
+            split4_store(areg[i], &sA[buf][off]);
+            split4_store(breg[i], &sB[buf][off]);
+        }
+    };
+
+    // transposing reads: lane 4q + c of a 16-lane group names pixel row q (of the lane half's 4j-th
+    // quartet) and channels 4c .. 4c+3 of the group's 16; the lane then holds ITS channel for those 4 pixels
+    const int tlane = (8 * h + ((lane & 15) >> 2)) * XROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    auto frag = [&](const unsigned char* tile, int block, int pl) -> bf16x8 {
+        const unsigned char* src = tile + pl * XPLANE + block * 64 + tlane;
+        const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src + 4 * XROWB));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    const int steps = (k_end - k_begin + XKP - 1) / XKP;
+    if (steps > 0) {
+        load_global(k_begin);
+        store_lds(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        const bool more = s + 1 < steps;
+        if (more) load_global(k_begin + (s + 1) * XKP);
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i][pl] = frag(sA[buf], wm * 2 + i, pl);
+                b[i][pl] = frag(sB[buf], wn * 2 + i, pl);
+            }
+        auto term = [&](int pa, int pb) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+        };
+        term(2, 0);
+        term(0, 2);
+        term(1, 1);
+        if (more) store_lds(buf ^ 1);
+        term(1, 0);
+        term(0, 1);
+        term(0, 0);
+        if ((s & (XFOLD - 1)) == XFOLD - 1 || !more) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    master[i][j] += acc[i][j];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                }
+        }
+        __syncthreads();
+    }
+
+    float* outp = p.out + static_cast<int64_t>(tap) * p.m_total * p.n_total;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + r;
+        if (n >= p.n_total) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < p.m_total) atomicAdd(outp + static_cast<int64_t>(m) * p.n_total + n, master[i][j][e]);
+            }
+    }
+}
+
 template <int MODE>
 int launch_wgrad(WgradParams& p, hipStream_t s) {
     const bool big = p.m_total > 64 || p.n_total > 64;
@@ -216,7 +430,7 @@ int launch_wgrad(WgradParams& p, hipStream_t s) {
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int64_t chunk = (p.k_total + splits - 1) / splits;
-    chunk = (chunk + BKP - 1) / BKP * BKP;
+    chunk = (chunk + BKP - 1) / BKP * BKP;   // a multiple of both kernels' K-steps (32 and 16 pixels)
     splits = (p.k_total + chunk - 1) / chunk;
     p.k_chunk = static_cast<int>(chunk);
     p.splits = static_cast<int>(splits);
@@ -227,7 +441,9 @@ int launch_wgrad(WgradParams& p, hipStream_t s) {
         ddpm::set_error("hipMemsetAsync: %s", hipGetErrorString(e));
         return DDPM_E_LAUNCH;
     }
-    if (big)
+    if (big && ddpm::split_math())
+        conv_wgrad_x3_kernel<MODE><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
+    else if (big)
         conv_wgrad_kernel<128, MODE><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
     else
         conv_wgrad_kernel<64, MODE><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);

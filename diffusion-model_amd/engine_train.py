@@ -34,6 +34,13 @@ class TrainMixin:
             self._sums = torch.empty(2 * 8 * self.base, dtype=torch.float32, device=dev)
         return self._ws
 
+    @staticmethod
+    def _wgrad_label(kind, m, n):
+        """Kernel family the library uses for a weight gradient (profiling label): tiles of 128 run on split-bf16."""
+        import os
+        split = (m > 64 or n > 64) and os.environ.get("DDPM_CONV_MATH") != "fp32"
+        return f"conv_wgrad<{kind},{'split-bf16' if split else 'fp32'}>"
+
     # ------------------------------------------------------------------ forward pieces
     def _conv_bn_fwd(self, V, src, conv_key, bn_key, cout, act, out, residual=None, temb=None, first=None):
         """conv3x3 (+bias) -> batch statistics -> normalise/affine (+residual) -> act (+temb)."""
@@ -184,7 +191,7 @@ class TrainMixin:
             return None, dres
         src = rec["src"]
         packed = torch.empty(wt.numel(), device=dev, dtype=torch.float32)
-        self._launch("conv_wgrad<conv3x3>", 2.0 * rows * cout * 9 * src.c, "ddpm_conv3x3_wgrad", draw.ptr, draw.ld, cout, src.ptr, src.ld,
+        self._launch(self._wgrad_label("conv3x3", cout, src.c), 2.0 * rows * cout * 9 * src.c, "ddpm_conv3x3_wgrad", draw.ptr, draw.ld, cout, src.ptr, src.ld,
                      src.c, b, h, w, _ptr(packed), _ptr(gw), _stream())
         grads[conv + ".weight"] = gw
         dsrc = None
@@ -218,7 +225,7 @@ class TrainMixin:
                      dqp, _stream())
         grads[key + ".gamma"] = dgamma
         gw = torch.empty((lq, c), device=dev, dtype=torch.float32)
-        self._launch("conv_wgrad<conv1x1>", 2.0 * b * n * lq * c, "ddpm_conv1x1_wgrad", dqkv.ptr, lq, lq, x.ptr, x.ld, c, b * n, _ptr(gw),
+        self._launch(self._wgrad_label("conv1x1", lq, c), 2.0 * b * n * lq * c, "ddpm_conv1x1_wgrad", dqkv.ptr, lq, lq, x.ptr, x.ld, c, b * n, _ptr(gw),
                      _stream())
         gb = torch.empty(lq, device=dev, dtype=torch.float32)
         call("ddpm_colsum", dqkv.ptr, lq, 1, b * n, lq, _ptr(ws), 0, _ptr(gb), _stream())
