@@ -195,7 +195,10 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             log(f"rank {rank}: entering barrier", True)
-            dist.barrier()
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
             torch.cuda.synchronize()
             log(f"rank {rank}: left barrier", True)
 
@@ -244,7 +247,7 @@ def main():
         assert state["loss"] == state["loss"], "loss is NaN"
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        parallel.all_reduce_(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     sec_per_step = dt / args.steps
     total_b = B * world
@@ -272,7 +275,8 @@ def main():
                                   "images/s = global_batch / (T * seconds_per_step)")
     else:
         cfg.update(optimizer="torch.optim.Adam(lr=2e-4)", batchnorm="per-rank batch statistics",
-                   parallelism=("dp%d: RCCL all-reduce of flattened gradients" % world) if world > 1 else "single GPU",
+                   parallelism=("dp%d: %s all-reduce of flattened gradients" % (world, "RCCL" if args.backend == "nccl" else args.backend))
+                   if world > 1 else "single GPU",
                    last_loss=round(state["loss"], 5))
     out = {
         "metric": wl["metric"], "value": round(value, 4), "unit": wl["unit"],

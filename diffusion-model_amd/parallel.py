@@ -22,13 +22,36 @@ def _world(group=None):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+def _host_staged(group=None):
+    """gloo moves host memory: device tensors are staged through the host for it (rehearsals of the
+    multi-process path on one GPU; RCCL takes device pointers directly)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_reduce_(t, op=None, group=None):
+    """In-place all-reduce of `t` on any backend."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 def broadcast_parameters(module, src=0, group=None):
     """Make every rank start from rank `src`'s parameters and buffers."""
     world, _ = _world(group)
     if world == 1:
         return
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        if t.is_cuda and _host_staged(group):
+            h = t.data.cpu()
+            dist.broadcast(h, src=src, group=group)
+            t.data.copy_(h)
+        else:
+            dist.broadcast(t.data, src=src, group=group)
 
 
 def average_gradients(params, group=None):
@@ -39,7 +62,7 @@ def average_gradients(params, group=None):
     if world == 1 or not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_(flat, group=group)
     flat.div_(world)
     off = 0
     for g in grads:
