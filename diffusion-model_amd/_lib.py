@@ -53,6 +53,7 @@ _SIGNATURES = {
     "ddpm_pack_conv3x3": [P, I32, I32, I32, P, P],
     "ddpm_pack_convT2x2": [P, I32, I32, P, P],
     "ddpm_pack_conv1x1": [P, I32, I32, I32, P, P],
+    "ddpm_pack_qkv": [P, P, P, P, P, P, I32, I32, I32, P, P, P, P],
     "ddpm_conv3x3_first_fwd": [P, P, C.POINTER(Epilogue), I32, P, I32, I32, I32, I32, I32, I32, P],
     "ddpm_conv1x1_final_fwd": [P, I32, P, P, P, I32, I32, I32, I32, I32, P],
     "ddpm_pool_skip_fwd": [P, I32, P, P, I32, P, I32, P, I32, I32, I32, I32, P],

@@ -768,6 +768,69 @@ __global__ void pack_split_kernel(const SplitPack a) {
     }
 }
 
+// Fused q|k|v projection weights of the attention block in one launch: the [2*dqp + C][C] weight
+// (q and k rows zero-padded from dq to dqp) packed for the forward 1x1 conv, its transpose packed for
+// the data-gradient GEMM, and the fused bias.
+struct QkvPack {
+    const float *qw, *kw, *vw, *qb, *kb, *vb;
+    float *out_f, *out_t, *bias;
+    int c, dq, dqp, split;
+};
+
+__device__ __forceinline__ float qkv_weight(const QkvPack& a, int n, int ch) {
+    if (n < a.dqp) return n < a.dq ? a.qw[n * a.c + ch] : 0.f;
+    if (n < 2 * a.dqp) return n - a.dqp < a.dq ? a.kw[(n - a.dqp) * a.c + ch] : 0.f;
+    return a.vw[(n - 2 * a.dqp) * a.c + ch];
+}
+
+__device__ __forceinline__ void store_split_element(unsigned short* out, int64_t i, float v) {
+    const unsigned u = __float_as_uint(v);
+    const float r1 = v - __uint_as_float(u & 0xffff0000u);
+    const unsigned m = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(m & 0xffff0000u);
+    unsigned short* o = out + (i >> 9) * 1536 + (i & 511);
+    o[0] = static_cast<unsigned short>(u >> 16);
+    o[512] = static_cast<unsigned short>(m >> 16);
+    o[1024] = static_cast<unsigned short>(__float_as_uint(r2) >> 16);
+}
+
+__global__ void pack_qkv_kernel(const QkvPack a) {
+    const int lq = 2 * a.dqp + a.c;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x, stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    if (a.split) {
+        // forward: rows = lq, depth = c
+        const int nbp = (lq + 31) / 32, kc16 = (a.c + 15) / 16;
+        for (int64_t i = t0; i < static_cast<int64_t>(kc16) * nbp * 512; i += stride) {
+            const int j = static_cast<int>(i & 7), fl = static_cast<int>((i >> 3) & 63);
+            const int nb = static_cast<int>((i >> 9) % nbp), kc = static_cast<int>((i >> 9) / nbp);
+            const int n = nb * 32 + (fl & 31), ch = kc * 16 + (fl >> 5) * 8 + j;
+            store_split_element(reinterpret_cast<unsigned short*>(a.out_f), i, (n < lq && ch < a.c) ? qkv_weight(a, n, ch) : 0.f);
+        }
+        // transpose: rows = c, depth = lq
+        const int nbt = (a.c + 31) / 32, kct = (lq + 15) / 16;
+        for (int64_t i = t0; i < static_cast<int64_t>(kct) * nbt * 512; i += stride) {
+            const int j = static_cast<int>(i & 7), fl = static_cast<int>((i >> 3) & 63);
+            const int nb = static_cast<int>((i >> 9) % nbt), kc = static_cast<int>((i >> 9) / nbt);
+            const int ch = nb * 32 + (fl & 31), n = kc * 16 + (fl >> 5) * 8 + j;
+            store_split_element(reinterpret_cast<unsigned short*>(a.out_t), i, (n < lq && ch < a.c) ? qkv_weight(a, n, ch) : 0.f);
+        }
+    } else {
+        for (int64_t i = t0; i < static_cast<int64_t>(lq) * a.c; i += stride) {
+            const int n = static_cast<int>(i / a.c), ch = static_cast<int>(i % a.c);
+            const float v = qkv_weight(a, n, ch);
+            a.out_f[i] = v;
+            a.out_t[static_cast<int64_t>(ch) * lq + n] = v;
+        }
+    }
+    for (int64_t n = t0; n < lq; n += stride) {
+        float v;
+        if (n < a.dqp) v = n < a.dq ? a.qb[n] : 0.f;
+        else if (n < 2 * a.dqp) v = n - a.dqp < a.dq ? a.kb[n - a.dqp] : 0.f;
+        else v = a.vb[n - 2 * a.dqp];
+        a.bias[n] = v;
+    }
+}
+
 int launch_split_pack(const float* w, float* out, int taps, int rows, int cin, int nq, long long base, long long st,
                       long long sq, long long sn, long long sc, hipStream_t s) {
     SplitPack a;
@@ -817,6 +880,21 @@ extern "C" int ddpm_pack_conv1x1(const float* w, int rows, int cin, int transpos
     const int grid = static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     copy_transpose_kernel<<<grid, 256, 0, as_stream(stream)>>>(w, rows, cin, transpose, out);
     return ddpm::check_launch("copy_transpose_kernel");
+}
+
+extern "C" int ddpm_pack_qkv(const float* qw, const float* kw, const float* vw, const float* qb, const float* kb, const float* vb,
+                             int c, int dq, int dqp, float* w_packed, float* wt_packed, float* bias, void* stream) {
+    DDPM_REQUIRE(qw && kw && vw && qb && kb && vb && w_packed && wt_packed && bias);
+    DDPM_REQUIRE(c > 0 && dq > 0 && dqp >= dq);
+    QkvPack a;
+    a.qw = qw; a.kw = kw; a.vw = vw; a.qb = qb; a.kb = kb; a.vb = vb;
+    a.out_f = w_packed; a.out_t = wt_packed; a.bias = bias;
+    a.c = c; a.dq = dq; a.dqp = dqp;
+    a.split = split_math() ? 1 : 0;
+    const int64_t total = static_cast<int64_t>(2 * dqp + c + 31) * (c + 31);
+    const int grid = static_cast<int>((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    pack_qkv_kernel<<<grid, 256, 0, as_stream(stream)>>>(a);
+    return ddpm::check_launch("pack_qkv_kernel");
 }
 
 extern "C" int ddpm_conv3x3_fwd(const ddpm_conv_desc* d, const float* src1, const float* src2, const float* w_packed,

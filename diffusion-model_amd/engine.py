@@ -183,13 +183,14 @@ class UNetEngine(TrainMixin):
             c = vw.shape[0]
             dq = qw.shape[0]
             dqp = _round_up(dq, 8)
-            w = torch.zeros(2 * dqp + c, c, device=vw.device, dtype=torch.float32)
-            b = torch.zeros(2 * dqp + c, device=vw.device, dtype=torch.float32)
-            w[:dq] = qw.reshape(dq, c)
-            w[dqp:dqp + dq] = kw.reshape(dq, c)
-            w[2 * dqp:] = vw.reshape(c, c)
-            b[:dq], b[dqp:dqp + dq], b[2 * dqp:] = qb, kb, vb
-            return pack_1x1(w, False), b, dqp, pack_1x1(w, True)
+            lq = 2 * dqp + c
+            dev = vw.device
+            wf = torch.empty(packed_floats(1, lq, c), device=dev, dtype=torch.float32)
+            wt = torch.empty(packed_floats(1, c, lq), device=dev, dtype=torch.float32)
+            b = torch.empty(lq, device=dev, dtype=torch.float32)
+            call("ddpm_pack_qkv", _ptr(qw.detach().contiguous()), _ptr(kw.detach().contiguous()), _ptr(vw.detach().contiguous()),
+                 _ptr(qb.detach()), _ptr(kb.detach()), _ptr(vb.detach()), c, dq, dqp, _ptr(wf), _ptr(wt), _ptr(b), _stream())
+            return wf, b, dqp, wt
         keys = tuple(f"{key}.{n}.{s}" for n in ("query", "key", "value") for s in ("weight", "bias"))
         return self._cached("qkv", keys, build)
 

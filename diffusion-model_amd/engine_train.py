@@ -58,7 +58,7 @@ class TrainMixin:
         invstd = torch.empty(cout, device=dev, dtype=torch.float32)
         call("ddpm_bn_stats", raw.ptr, raw.ld, b * h * w, cout, BN_EPS, BN_MOMENTUM, _ptr(self._workspace(dev)), _ptr(mean),
              _ptr(invstd), _ptr(self.T(bn_key + ".running_mean")), _ptr(self.T(bn_key + ".running_var")), _stream())
-        self.T(bn_key + ".num_batches_tracked").add_(1)
+        self._nbt.append(self.T(bn_key + ".num_batches_tracked"))    # incremented together at the end of the forward
         call("ddpm_bn_apply_fwd", raw.ptr, raw.ld, _ptr(mean), _ptr(invstd), _ptr(self.T(bn_key + ".weight")),
              _ptr(self.T(bn_key + ".bias")), residual.ptr if residual is not None else None,
              residual.ld if residual is not None else 0, _ptr(temb), act, out.ptr, out.ld, b, h * w, cout, _stream())
@@ -101,6 +101,7 @@ class TrainMixin:
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         fms = []
         tape = dict(x=x, t=t, y=y, emb=emb, shape=(B, H, W))
+        self._nbt = []
 
         def buf(h, w, c):
             return torch.empty((B, h, w, c), device=dev, dtype=torch.float32)
@@ -161,6 +162,8 @@ class TrainMixin:
         call("ddpm_conv1x1_final_fwd", hcur.ptr, hcur.ld, _ptr(self.T("final_conv.weight")), _ptr(self.T("final_conv.bias")),
              _ptr(out), B, H, W, bc, self.cout_final, _stream())
         tape["final_in"] = hcur
+        torch._foreach_add_(self._nbt, 1)
+        self._nbt = []
         return out, [f.nchw() for f in fms], tape
 
     # ------------------------------------------------------------------ backward pieces

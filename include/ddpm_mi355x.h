@@ -189,6 +189,15 @@ int ddpm_pack_conv3x3(const float* w, int cout, int cin, int flip, float* out, v
 int ddpm_pack_convT2x2(const float* w, int cin, int cout, float* out, void* stream);
 int ddpm_pack_conv1x1(const float* w, int rows, int cin, int transpose, float* out, void* stream);
 
+/* The attention block's three 1x1 projections as ONE GEMM (second-iteration/unet.py:45-47): packs
+ * the fused [2*dqp + C][C] weight (query | key | value rows, query/key zero-padded from dq = C/8 to
+ * dqp rows) for ddpm_conv1x1_fwd into w_packed (ddpm_packed_weight_floats(1, 2*dqp + C, C) floats),
+ * its transpose for the data-gradient GEMM into wt_packed (ddpm_packed_weight_floats(1, C, 2*dqp + C)
+ * floats) and the fused bias [2*dqp + C]. Weights in torch layout [rows][C] (the 1x1 kernel dims dropped). */
+int ddpm_pack_qkv(const float* qw, const float* kw, const float* vw, const float* qb, const float* kb,
+                  const float* vb, int c, int dq, int dqp, float* w_packed, float* wt_packed, float* bias,
+                  void* stream);
+
 /* First layer: 3x3 pad 1 on an NCHW input with few channels (1 or 3), direct (non-MFMA),
  * writes NHWC with the same epilogue. w: torch layout [cout][cin][3][3].
  * Replaces the first Conv2d of enc1, first-iteration/unet.py:61. */
