@@ -629,9 +629,438 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_fast_kernel(const BwdParam
     }
 }
 
+
+// ---- split-bf16 variants of the fast paths -------------------------------------------------------
+// Same mathematics and wave ownership as the fast kernels above, on v_mfma_f32_32x32x16_bf16: every
+// fp32 operand is the exact sum of three bf16 numbers (hi + mid + lo) and a product is evaluated as
+// its six cross terms of weight >= 2^-16 with fp32 accumulation (dropped terms below 2^-23 of the
+// product). Tiles that stream past are split on their way to LDS (three bf16 planes); the wave's
+// fixed operand is split once into registers; P and dS are split in registers and, being in the
+// accumulator layout (lane = column, register = row), serve as B operands as they stand. The
+// operands that the fp32 kernels fetched with one 4-byte LDS read per MFMA (dO^T, Q^T, K^T) come from
+// the transposing read ds_read_b64_tr_b16, in the key/query order the score registers hold.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+    unsigned u[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        u[e] = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(u[e] & 0xffff0000u);
+        m[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(m[e] & 0xffff0000u);
+        l[e] = __float_as_uint(r2);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = __builtin_amdgcn_perm(u[2 * e + 1], u[2 * e], 0x07060302u);
+        mid[e] = __builtin_amdgcn_perm(m[2 * e + 1], m[2 * e], 0x07060302u);
+        lo[e] = __builtin_amdgcn_perm(l[2 * e + 1], l[2 * e], 0x07060302u);
+    }
+}
+
+__device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst, int plane_stride) {
+    unsigned u[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        u[e] = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(u[e] & 0xffff0000u);
+        m[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(m[e] & 0xffff0000u);
+        l[e] = __float_as_uint(r2);
+    }
+    u32x2 hi, mid, lo;
+    hi[0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
+    hi[1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
+    mid[0] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
+    mid[1] = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
+    lo[0] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
+    lo[1] = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
+    *reinterpret_cast<u32x2*>(dst) = hi;
+    *reinterpret_cast<u32x2*>(dst + plane_stride) = mid;
+    *reinterpret_cast<u32x2*>(dst + 2 * plane_stride) = lo;
+}
+
+// 8 floats at p (two float4; zeros when !ok) -> three planes
+__device__ __forceinline__ void load_split8(const float* p, bool ok, u32x4& hi, u32x4& mid, u32x4& lo, float scale) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (ok) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = a[j] * scale;
+            v[4 + j] = b[j] * scale;
+        }
+    }
+    split8(v, hi, mid, lo);
+}
+
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* a0, const unsigned char* a1) {
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// 256-byte rows of 16-bit elements read both row-wise (ds_read_b128) and transposed (ds_read_b64_tr_b16):
+// 16-byte chunk ch of row `row` lives at this offset; both kinds of read are then bank-conflict-free.
+__device__ __forceinline__ int swz(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+constexpr int kWideRow = 256;                 // bytes per row of a swizzled plane (128 channels; 64 use half)
+constexpr int kWidePlane = 32 * kWideRow;     // one plane of a 32-row tile
+constexpr int kNarrowPlane = 32 * 32;         // 32 rows x 16 depth values (Q or K tile), 32-byte rows
+
+template <int DQ, int CT>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const BwdParams p) {
+    constexpr int NCT = CT / 32, KCV = CT / 16;
+    constexpr int DOPT = TQ * CT / 4 / 256;   // dO float4 per thread
+    constexpr int QF4 = TQ * DQ / 4;          // Q float4 per tile (<= 256)
+    __shared__ __attribute__((aligned(256))) unsigned char sDO[2][3 * kWidePlane];
+    __shared__ __attribute__((aligned(16))) unsigned char sQ[2][3 * kNarrowPlane];
+    __shared__ __attribute__((aligned(16))) float sL[2][TQ], sD[2][TQ];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int j0 = (blockIdx.x * 4 + wave) * 32;
+    const bool wave_active = j0 < p.n;
+    const int kj = j0 + r;
+    const bool k_ok = kj < p.n;
+    const float g = p.gamma[0];
+    const float* base = p.qkv + static_cast<int64_t>(b) * p.n * p.lq;
+    const float* dyb = p.dy + static_cast<int64_t>(b) * p.n * p.ldd;
+    const float* lseb = p.lse + static_cast<int64_t>(b) * p.n;
+    const float* eb = p.e + static_cast<int64_t>(b) * p.n;
+
+    if (DQ < 16) {   // the upper half of the padded depth of the Q tile stays zero
+        for (int i = tid; i < 2 * 3 * kNarrowPlane / 4; i += 256) reinterpret_cast<unsigned*>(&sQ[0][0])[i] = 0u;
+    }
+
+    // fixed operands of this wave's 32 keys: lane (key, h) holds depth / channels 16*chunk + 8h .. + 7
+    u32x4 kf[3], vf[KCV][3];
+    load_split8(base + static_cast<int64_t>(kj) * p.lq + DQ + 8 * h, k_ok && 8 * h < DQ, kf[0], kf[1], kf[2], 1.0f);
+#pragma unroll
+    for (int kc = 0; kc < KCV; ++kc)
+        load_split8(base + static_cast<int64_t>(kj) * p.lq + 2 * DQ + 16 * kc + 8 * h, k_ok, vf[kc][0], vf[kc][1], vf[kc][2], 1.0f);
+
+    f32x16 dv[NCT], dk;
+#pragma unroll
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dv[t][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dk[e] = 0.f;
+
+    f32x4 doreg[DOPT], qreg;
+    float lreg = 0.f, dreg = 0.f;
+    auto load_tile = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < DOPT; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (CT / 4), c4 = f % (CT / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i0 + row < p.n) v = *reinterpret_cast<const f32x4*>(dyb + static_cast<int64_t>(i0 + row) * p.ldd + c4 * 4);
+            doreg[i] = v * g;
+        }
+        if (tid < QF4) {
+            const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i0 + row < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(i0 + row) * p.lq + c4 * 4);
+            qreg = v;
+        }
+        if (tid < TQ) {
+            const bool ok = i0 + tid < p.n;
+            lreg = ok ? lseb[i0 + tid] : 0.f;
+            dreg = ok ? g * eb[i0 + tid] : 0.f;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < DOPT; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (CT / 4), c4 = f % (CT / 4);
+            split4_store(doreg[i], &sDO[buf][swz(row, c4 >> 1) + 8 * (c4 & 1)], kWidePlane);
+        }
+        if (tid < QF4) {
+            const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
+            split4_store(qreg, &sQ[buf][row * 32 + c4 * 8], kNarrowPlane);
+        }
+        if (tid < TQ) {
+            sL[buf][tid] = lreg;
+            sD[buf][tid] = dreg;
+        }
+    };
+
+    // lane-constant parts of the LDS addresses
+    const int sw_row = ((r & 3) << 2) | ((r >> 2) & 3);       // swizzle of row r (row reads)
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;   // transposed reads: row quartet, column quad, column group
+    // transposed read of a 32-row tile: rows 16*ck + 4h + tq (+8 for the second half); row & 3 = tq, (row >> 2) & 3 = h (+2)
+    const int tsw0 = (tq << 2) | (h & 3), tsw1 = (tq << 2) | ((h + 2) & 3);
+    const int qtr = (4 * h + tq) * 32 + tp * 8;               // Q tile: 32-byte rows, 16 depth values; column group ignored (rows >= DQ are discarded)
+
+    const int qtiles = (p.n + TQ - 1) / TQ;
+    load_tile(0);
+    __syncthreads();
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < qtiles; ++t) {
+        const int buf = t & 1, i0 = t * TQ;
+        const bool more = t + 1 < qtiles;
+        if (more) load_tile(i0 + TQ);
+        if (wave_active) {
+            const unsigned char* q = sQ[buf];
+            const unsigned char* dO = sDO[buf];
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+            auto six = [&](f32x16& acc, const bf16x8 (&a)[3], const u32x4 (&bb)[3]) {
+                const int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[k]], __builtin_bit_cast(bf16x8, bb[pb[k]]), acc, 0, 0, 0);
+            };
+            {   // S = Q K^T: rows = queries (this tile), columns = keys (lanes)
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(q + pl * kNarrowPlane + r * 32 + h * 16);
+                six(s, a, kf);
+            }
+#pragma unroll
+            for (int kc = 0; kc < KCV; ++kc) {   // dP = dO V^T
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(dO + pl * kWidePlane + 256 * r + 16 * ((2 * kc + h) ^ sw_row));
+                six(dp, a, vf[kc]);
+            }
+            // P and dS, split into planes per 16-query chunk (register e <-> query rowmap(e, h))
+            u32x4 pp[2][3], ds[2][3];
+#pragma unroll
+            for (int ck = 0; ck < 2; ++ck) {
+                float pv[8], dsv[8];
+#pragma unroll
+                for (int g4 = 0; g4 < 2; ++g4) {
+                    const int il0 = 16 * ck + 8 * g4 + 4 * h;   // queries il0 .. il0 + 3 = registers 8ck + 4g4 .. + 3
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(&sL[buf][il0]);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sD[buf][il0]);
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const int e = 8 * ck + 4 * g4 + e4;
+                        const bool ok = (i0 + il0 + e4 < p.n) && k_ok;
+                        const float pe = ok ? __builtin_amdgcn_exp2f((s[e] - l4[e4]) * 1.4426950408889634f) : 0.f;
+                        pv[4 * g4 + e4] = pe;
+                        dsv[4 * g4 + e4] = pe * (dp[e] - d4[e4]);
+                    }
+                }
+                split8(pv, pp[ck][0], pp[ck][1], pp[ck][2]);
+                split8(dsv, ds[ck][0], ds[ck][1], ds[ck][2]);
+            }
+#pragma unroll
+            for (int ck = 0; ck < 2; ++ck) {
+                // dV^T += dO^T P : A = dO^T through transposed reads (rows = channels of block ct, k = queries)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    bf16x8 a[3];
+                    const int row0 = 16 * ck + 4 * h + tq;
+                    const int ch0 = 4 * ct + 2 * tg + (tp >> 1);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const unsigned char* pb = dO + pl * kWidePlane + 8 * (tp & 1);
+                        a[pl] = tr_pair(pb + 256 * row0 + 16 * (ch0 ^ tsw0), pb + 256 * (row0 + 8) + 16 * (ch0 ^ tsw1));
+                    }
+                    six(dv[ct], a, pp[ck]);
+                }
+                // dK^T += Q^T dS
+                {
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const unsigned char* pb = q + pl * kNarrowPlane + 16 * ck * 32 + qtr;
+                        a[pl] = tr_pair(pb, pb + 8 * 32);
+                    }
+                    six(dk, a, ds[ck]);
+                }
+            }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (!wave_active || !k_ok) return;
+    float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + kj) * p.lq;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int ch = ct * 32 + gq * 8 + h * 4;
+            f32x4 v = {dv[ct][gq * 4], dv[ct][gq * 4 + 1], dv[ct][gq * 4 + 2], dv[ct][gq * 4 + 3]};
+            *reinterpret_cast<f32x4*>(drow + 2 * DQ + ch) = v;
+        }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int d = gq * 8 + h * 4;
+        if (d >= DQ) continue;
+        f32x4 v = {dk[gq * 4], dk[gq * 4 + 1], dk[gq * 4 + 2], dk[gq * 4 + 3]};
+        *reinterpret_cast<f32x4*>(drow + DQ + d) = v;
+    }
+}
+
+template <int DQ, int CT>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams p) {
+    constexpr int KCV = CT / 16;
+    constexpr int VROW = CT * 2 + 16;          // V plane row + pad: row reads conflict-free
+    constexpr int VPLANE = 32 * VROW;
+    constexpr int VPT = 32 * CT / 4 / 256;
+    constexpr int KF4 = 32 * DQ / 4;
+    __shared__ __attribute__((aligned(16))) unsigned char sK[2][3 * kNarrowPlane];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[2][3 * VPLANE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int i0 = (blockIdx.x * 4 + wave) * 32;
+    const bool wave_active = i0 < p.n;
+    const int qi = i0 + r;
+    const bool q_ok = qi < p.n;
+    const float g = p.gamma[0];
+    const float* base = p.qkv + static_cast<int64_t>(b) * p.n * p.lq;
+
+    if (DQ < 16) {
+        for (int i = tid; i < 2 * 3 * kNarrowPlane / 4; i += 256) reinterpret_cast<unsigned*>(&sK[0][0])[i] = 0u;
+    }
+
+    // fixed operands of this wave's 32 queries: lane (query, h) holds depth / channels 16*chunk + 8h .. + 7
+    u32x4 qf[3], dof[KCV][3];
+    load_split8(base + static_cast<int64_t>(qi) * p.lq + 8 * h, q_ok && 8 * h < DQ, qf[0], qf[1], qf[2], 1.0f);
+#pragma unroll
+    for (int kc = 0; kc < KCV; ++kc)
+        load_split8(p.dy + (static_cast<int64_t>(b) * p.n + qi) * p.ldd + 16 * kc + 8 * h, q_ok, dof[kc][0], dof[kc][1], dof[kc][2], g);
+    const float lse_i = q_ok ? p.lse[static_cast<int64_t>(b) * p.n + qi] : 0.f;
+    const float d_i = q_ok ? g * p.e[static_cast<int64_t>(b) * p.n + qi] : 0.f;
+
+    f32x16 dq;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+
+    f32x4 kreg, vreg[VPT];
+    auto load_tile = [&](int j0) {
+        if (tid < KF4) {
+            const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + row < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(j0 + row) * p.lq + DQ + c4 * 4);
+            kreg = v;
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (CT / 4), c4 = f % (CT / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + row < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(j0 + row) * p.lq + 2 * DQ + c4 * 4);
+            vreg[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        if (tid < KF4) {
+            const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
+            split4_store(kreg, &sK[buf][row * 32 + c4 * 8], kNarrowPlane);
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (CT / 4), c4 = f % (CT / 4);
+            split4_store(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE);
+        }
+    };
+
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int ktr = (4 * h + tq) * 32 + tp * 8;   // K tile transposed read: rows = keys 4h + tq (+8, +16 per chunk), 16 depth columns
+
+    const int ktiles = (p.n + 31) / 32;
+    load_tile(0);
+    __syncthreads();
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ktiles; ++t) {
+        const int buf = t & 1, j0 = t * 32;
+        const bool more = t + 1 < ktiles;
+        if (more) load_tile(j0 + 32);
+        if (wave_active) {
+            const unsigned char* k = sK[buf];
+            const unsigned char* v = sV[buf];
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+            auto six = [&](f32x16& acc, const bf16x8 (&a)[3], const u32x4 (&bb)[3]) {
+                const int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[kk]], __builtin_bit_cast(bf16x8, bb[pb[kk]]), acc, 0, 0, 0);
+            };
+            {   // S^T = K Q^T: rows = keys (this tile), columns = queries (lanes)
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(k + pl * kNarrowPlane + r * 32 + h * 16);
+                six(s, a, qf);
+            }
+#pragma unroll
+            for (int kc = 0; kc < KCV; ++kc) {   // dP^T = V dO^T
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(v + pl * VPLANE + r * VROW + kc * 32 + h * 16);
+                six(dp, a, dof[kc]);
+            }
+            u32x4 ds[2][3];
+#pragma unroll
+            for (int ck = 0; ck < 2; ++ck) {
+                float dsv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 8 * ck + j;
+                    const bool ok = q_ok && (j0 + rowmap(e, h) < p.n);
+                    const float pe = ok ? __builtin_amdgcn_exp2f((s[e] - lse_i) * 1.4426950408889634f) : 0.f;
+                    dsv[j] = pe * (dp[e] - d_i);
+                }
+                split8(dsv, ds[ck][0], ds[ck][1], ds[ck][2]);
+            }
+#pragma unroll
+            for (int ck = 0; ck < 2; ++ck) {   // dQ^T += K^T dS^T
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const unsigned char* pb = k + pl * kNarrowPlane + 16 * ck * 32 + ktr;
+                    a[pl] = tr_pair(pb, pb + 8 * 32);
+                }
+                six(dq, a, ds[ck]);
+            }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    if (!wave_active || !q_ok) return;
+    float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + qi) * p.lq;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int d = gq * 8 + h * 4;
+        if (d >= DQ) continue;
+        f32x4 v = {dq[gq * 4], dq[gq * 4 + 1], dq[gq * 4 + 2], dq[gq * 4 + 3]};
+        *reinterpret_cast<f32x4*>(drow + d) = v;
+    }
+}
+
 template <int DQ, int CT>
 int launch_bwd_fast(const BwdParams& p, int batch, hipStream_t s) {
     const dim3 grid((p.n + 127) / 128, 1, batch);
+    if (ddpm::split_math()) {
+        attn_bwd_dkv_x3_kernel<DQ, CT><<<grid, 256, 0, s>>>(p);
+        attn_bwd_dq_x3_kernel<DQ, CT><<<grid, 256, 0, s>>>(p);
+        return ddpm::check_launch("attn_bwd_x3");
+    }
 #ifndef DDPM_DKV_WPS
 #define DDPM_DKV_WPS 1
 #endif
