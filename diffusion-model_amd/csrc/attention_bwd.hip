@@ -711,51 +711,66 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* a0, const unsigne
 // 16-byte chunk ch of row `row` lives at this offset; both kinds of read are then bank-conflict-free.
 __device__ __forceinline__ int swz(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-constexpr int kWideRow = 256;                 // bytes per row of a swizzled plane (128 channels; 64 use half)
-constexpr int kWidePlane = 32 * kWideRow;     // one plane of a 32-row tile
-constexpr int kNarrowPlane = 32 * 32;         // 32 rows x 16 depth values (Q or K tile), 32-byte rows
-
-template <int DQ, int CT>
+// Key-side gradients of 32 keys per wave. DK: dK (needs dP, hence V of all CT = C channels in
+// registers; the dO tile is only read row-wise and sits in padded rows). DV: dV for the CT channels
+// starting at blockIdx.y * CT (CT <= 128; the dO tile is read transposed and sits in swizzled 256-byte
+// rows). Both at once when the registers allow (C <= 128); wider layers run the two halves as separate
+// launches, each recomputing the scores (depth-DQ products, cheap beside the C-deep ones).
+template <int DQ, int CT, bool DK, bool DV>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const BwdParams p) {
+    static_assert(!DV || CT <= 128, "transposed dO reads assume 256-byte rows");
     constexpr int NCT = CT / 32, KCV = CT / 16;
-    constexpr int DOPT = TQ * CT / 4 / 256;   // dO float4 per thread
-    constexpr int QF4 = TQ * DQ / 4;          // Q float4 per tile (<= 256)
-    __shared__ __attribute__((aligned(256))) unsigned char sDO[2][3 * kWidePlane];
-    __shared__ __attribute__((aligned(16))) unsigned char sQ[2][3 * kNarrowPlane];
-    __shared__ __attribute__((aligned(16))) float sL[2][TQ], sD[2][TQ];
+    constexpr int KD = DQ < 16 ? 16 : DQ, KQ = KD / 16;   // padded depth, 16-deep chunks of it
+    constexpr int QROW = 2 * KD, QPLANE = 32 * QROW;      // bytes
+    constexpr int DROW = DV ? 256 : CT * 2 + 16, DPLANE = 32 * DROW;
+    constexpr int DOPT = TQ * CT / 4 / 256;               // dO float4 per thread
+    constexpr int QF4 = TQ * DQ / 4;                      // Q float4 per tile (<= 256)
+    extern __shared__ __attribute__((aligned(256))) unsigned char dyn_lds[];
+    unsigned char* sDO = dyn_lds;                          // [2][3 * DPLANE]
+    unsigned char* sQ = sDO + 2 * 3 * DPLANE;              // [2][3 * QPLANE]
+    float* sL = reinterpret_cast<float*>(sQ + 2 * 3 * QPLANE);   // [2][TQ]
+    float* sD = sL + 2 * TQ;                               // [2][TQ]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z;
+    const int c0 = blockIdx.y * CT;
     const int j0 = (blockIdx.x * 4 + wave) * 32;
     const bool wave_active = j0 < p.n;
     const int kj = j0 + r;
     const bool k_ok = kj < p.n;
     const float g = p.gamma[0];
     const float* base = p.qkv + static_cast<int64_t>(b) * p.n * p.lq;
-    const float* dyb = p.dy + static_cast<int64_t>(b) * p.n * p.ldd;
+    const float* dyb = p.dy + static_cast<int64_t>(b) * p.n * p.ldd + c0;
     const float* lseb = p.lse + static_cast<int64_t>(b) * p.n;
     const float* eb = p.e + static_cast<int64_t>(b) * p.n;
 
     if (DQ < 16) {   // the upper half of the padded depth of the Q tile stays zero
-        for (int i = tid; i < 2 * 3 * kNarrowPlane / 4; i += 256) reinterpret_cast<unsigned*>(&sQ[0][0])[i] = 0u;
+        for (int i = tid; i < 2 * 3 * QPLANE / 4; i += 256) reinterpret_cast<unsigned*>(sQ)[i] = 0u;
     }
 
     // fixed operands of this wave's 32 keys: lane (key, h) holds depth / channels 16*chunk + 8h .. + 7
-    u32x4 kf[3], vf[KCV][3];
-    load_split8(base + static_cast<int64_t>(kj) * p.lq + DQ + 8 * h, k_ok && 8 * h < DQ, kf[0], kf[1], kf[2], 1.0f);
+    u32x4 kf[KQ][3], vf[DK ? KCV : 1][3];
 #pragma unroll
-    for (int kc = 0; kc < KCV; ++kc)
-        load_split8(base + static_cast<int64_t>(kj) * p.lq + 2 * DQ + 16 * kc + 8 * h, k_ok, vf[kc][0], vf[kc][1], vf[kc][2], 1.0f);
+    for (int kq = 0; kq < KQ; ++kq)
+        load_split8(base + static_cast<int64_t>(kj) * p.lq + DQ + 16 * kq + 8 * h, k_ok && 16 * kq + 8 * h < DQ, kf[kq][0], kf[kq][1],
+                    kf[kq][2], 1.0f);
+    if (DK) {
+#pragma unroll
+        for (int kc = 0; kc < KCV; ++kc)
+            load_split8(base + static_cast<int64_t>(kj) * p.lq + 2 * DQ + 16 * kc + 8 * h, k_ok, vf[kc][0], vf[kc][1], vf[kc][2], 1.0f);
+    }
 
-    f32x16 dv[NCT], dk;
+    f32x16 dv[DV ? NCT : 1], dk;
 #pragma unroll
-    for (int t = 0; t < NCT; ++t)
+    for (int t = 0; t < (DV ? NCT : 1); ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dv[t][e] = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) dk[e] = 0.f;
+
+    auto dofs = [](int row, int ch) { return DV ? swz(row, ch) : row * DROW + 16 * ch; };
 
     f32x4 doreg[DOPT], qreg;
     float lreg = 0.f, dreg = 0.f;
@@ -785,24 +800,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const BwdParams
         for (int i = 0; i < DOPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CT / 4), c4 = f % (CT / 4);
-            split4_store(doreg[i], &sDO[buf][swz(row, c4 >> 1) + 8 * (c4 & 1)], kWidePlane);
+            split4_store(doreg[i], sDO + buf * 3 * DPLANE + dofs(row, c4 >> 1) + 8 * (c4 & 1), DPLANE);
         }
         if (tid < QF4) {
             const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
-            split4_store(qreg, &sQ[buf][row * 32 + c4 * 8], kNarrowPlane);
+            split4_store(qreg, sQ + buf * 3 * QPLANE + row * QROW + c4 * 8, QPLANE);
         }
         if (tid < TQ) {
-            sL[buf][tid] = lreg;
-            sD[buf][tid] = dreg;
+            sL[buf * TQ + tid] = lreg;
+            sD[buf * TQ + tid] = dreg;
         }
     };
 
     // lane-constant parts of the LDS addresses
-    const int sw_row = ((r & 3) << 2) | ((r >> 2) & 3);       // swizzle of row r (row reads)
+    const int sw_row = DV ? (((r & 3) << 2) | ((r >> 2) & 3)) : 0;        // swizzle of row r (row reads)
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;   // transposed reads: row quartet, column quad, column group
     // transposed read of a 32-row tile: rows 16*ck + 4h + tq (+8 for the second half); row & 3 = tq, (row >> 2) & 3 = h (+2)
     const int tsw0 = (tq << 2) | (h & 3), tsw1 = (tq << 2) | ((h + 2) & 3);
-    const int qtr = (4 * h + tq) * 32 + tp * 8;               // Q tile: 32-byte rows, 16 depth values; column group ignored (rows >= DQ are discarded)
+    // Q tile: QROW-byte rows of KD depth values; with KD = 16 the second column group (depth rows >= 16) is never stored
+    const int qtr = (4 * h + tq) * QROW + tp * 8 + (KD > 16 ? tg * 32 : 0);
 
     const int qtiles = (p.n + TQ - 1) / TQ;
     load_tile(0);
@@ -814,8 +830,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const BwdParams
         const bool more = t + 1 < qtiles;
         if (more) load_tile(i0 + TQ);
         if (wave_active) {
-            const unsigned char* q = sQ[buf];
-            const unsigned char* dO = sDO[buf];
+            const unsigned char* q = sQ + buf * 3 * QPLANE;
+            const unsigned char* dO = sDO + buf * 3 * DPLANE;
             f32x16 s, dp;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
@@ -825,18 +841,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const BwdParams
                 for (int k = 0; k < 6; ++k)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[k]], __builtin_bit_cast(bf16x8, bb[pb[k]]), acc, 0, 0, 0);
             };
-            {   // S = Q K^T: rows = queries (this tile), columns = keys (lanes)
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) {   // S = Q K^T: rows = queries (this tile), columns = keys (lanes)
                 bf16x8 a[3];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(q + pl * kNarrowPlane + r * 32 + h * 16);
-                six(s, a, kf);
+                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(q + pl * QPLANE + r * QROW + kq * 32 + h * 16);
+                six(s, a, kf[kq]);
             }
+            if (DK) {
 #pragma unroll
-            for (int kc = 0; kc < KCV; ++kc) {   // dP = dO V^T
-                bf16x8 a[3];
+                for (int kc = 0; kc < KCV; ++kc) {   // dP = dO V^T
+                    bf16x8 a[3];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(dO + pl * kWidePlane + 256 * r + 16 * ((2 * kc + h) ^ sw_row));
-                six(dp, a, vf[kc]);
+                    for (int pl = 0; pl < 3; ++pl)
+                        a[pl] = *reinterpret_cast<const bf16x8*>(dO + pl * DPLANE + r * DROW + 16 * ((2 * kc + h) ^ sw_row));
+                    six(dp, a, vf[kc]);
+                }
             }
             // P and dS, split into planes per 16-query chunk (register e <-> query rowmap(e, h))
             u32x4 pp[2][3], ds[2][3];
@@ -846,8 +866,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const BwdParams
 #pragma unroll
                 for (int g4 = 0; g4 < 2; ++g4) {
                     const int il0 = 16 * ck + 8 * g4 + 4 * h;   // queries il0 .. il0 + 3 = registers 8ck + 4g4 .. + 3
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(&sL[buf][il0]);
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sD[buf][il0]);
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(&sL[buf * TQ + il0]);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sD[buf * TQ + il0]);
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) {
                         const int e = 8 * ck + 4 * g4 + e4;
@@ -857,31 +877,32 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const BwdParams
                         dsv[4 * g4 + e4] = pe * (dp[e] - d4[e4]);
                     }
                 }
-                split8(pv, pp[ck][0], pp[ck][1], pp[ck][2]);
-                split8(dsv, ds[ck][0], ds[ck][1], ds[ck][2]);
+                if (DV) split8(pv, pp[ck][0], pp[ck][1], pp[ck][2]);
+                if (DK) split8(dsv, ds[ck][0], ds[ck][1], ds[ck][2]);
             }
 #pragma unroll
             for (int ck = 0; ck < 2; ++ck) {
-                // dV^T += dO^T P : A = dO^T through transposed reads (rows = channels of block ct, k = queries)
+                if (DV) {
+                    // dV^T += dO^T P : A = dO^T through transposed reads (rows = channels of block ct, k = queries)
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    bf16x8 a[3];
-                    const int row0 = 16 * ck + 4 * h + tq;
-                    const int ch0 = 4 * ct + 2 * tg + (tp >> 1);
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        bf16x8 a[3];
+                        const int row0 = 16 * ck + 4 * h + tq;
+                        const int ch0 = 4 * ct + 2 * tg + (tp >> 1);
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        const unsigned char* pb = dO + pl * kWidePlane + 8 * (tp & 1);
-                        a[pl] = tr_pair(pb + 256 * row0 + 16 * (ch0 ^ tsw0), pb + 256 * (row0 + 8) + 16 * (ch0 ^ tsw1));
+                        for (int pl = 0; pl < 3; ++pl) {
+                            const unsigned char* pb = dO + pl * DPLANE + 8 * (tp & 1);
+                            a[pl] = tr_pair(pb + 256 * row0 + 16 * (ch0 ^ tsw0), pb + 256 * (row0 + 8) + 16 * (ch0 ^ tsw1));
+                        }
+                        six(dv[ct], a, pp[ck]);
                     }
-                    six(dv[ct], a, pp[ck]);
                 }
-                // dK^T += Q^T dS
-                {
+                if (DK) {   // dK^T += Q^T dS
                     bf16x8 a[3];
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
-                        const unsigned char* pb = q + pl * kNarrowPlane + 16 * ck * 32 + qtr;
-                        a[pl] = tr_pair(pb, pb + 8 * 32);
+                        const unsigned char* pb = q + pl * QPLANE + 16 * ck * QROW + qtr;
+                        a[pl] = tr_pair(pb, pb + 8 * QROW);
                     }
                     six(dk, a, ds[ck]);
                 }
@@ -893,32 +914,46 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const BwdParams
 
     if (!wave_active || !k_ok) return;
     float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + kj) * p.lq;
+    if (DV) {
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int ch = c0 + ct * 32 + gq * 8 + h * 4;
+                f32x4 v = {dv[ct][gq * 4], dv[ct][gq * 4 + 1], dv[ct][gq * 4 + 2], dv[ct][gq * 4 + 3]};
+                *reinterpret_cast<f32x4*>(drow + 2 * DQ + ch) = v;
+            }
+    }
+    if (DK) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            const int ch = ct * 32 + gq * 8 + h * 4;
-            f32x4 v = {dv[ct][gq * 4], dv[ct][gq * 4 + 1], dv[ct][gq * 4 + 2], dv[ct][gq * 4 + 3]};
-            *reinterpret_cast<f32x4*>(drow + 2 * DQ + ch) = v;
+            const int d = gq * 8 + h * 4;
+            if (d >= DQ) continue;
+            f32x4 v = {dk[gq * 4], dk[gq * 4 + 1], dk[gq * 4 + 2], dk[gq * 4 + 3]};
+            *reinterpret_cast<f32x4*>(drow + DQ + d) = v;
         }
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        const int d = gq * 8 + h * 4;
-        if (d >= DQ) continue;
-        f32x4 v = {dk[gq * 4], dk[gq * 4 + 1], dk[gq * 4 + 2], dk[gq * 4 + 3]};
-        *reinterpret_cast<f32x4*>(drow + DQ + d) = v;
     }
 }
 
+template <int DQ, int CT, bool DK, bool DV>
+constexpr int dkv_x3_lds() {
+    constexpr int KD = DQ < 16 ? 16 : DQ;
+    return 2 * 3 * 32 * (DV ? 256 : CT * 2 + 16) + 2 * 3 * 32 * 2 * KD + 4 * TQ * 4;
+}
+
+// Query-side gradient of 32 queries per wave (dO of all CT = C channels in registers).
 template <int DQ, int CT>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams p) {
     constexpr int KCV = CT / 16;
+    constexpr int KD = DQ < 16 ? 16 : DQ, KQ = KD / 16;
+    constexpr int KROW = 2 * KD, KPLANE = 32 * KROW;
     constexpr int VROW = CT * 2 + 16;          // V plane row + pad: row reads conflict-free
     constexpr int VPLANE = 32 * VROW;
     constexpr int VPT = 32 * CT / 4 / 256;
     constexpr int KF4 = 32 * DQ / 4;
-    __shared__ __attribute__((aligned(16))) unsigned char sK[2][3 * kNarrowPlane];
-    __shared__ __attribute__((aligned(16))) unsigned char sV[2][3 * VPLANE];
+    extern __shared__ __attribute__((aligned(256))) unsigned char dyn_lds[];
+    unsigned char* sV = dyn_lds;                  // [2][3 * VPLANE]
+    unsigned char* sK = sV + 2 * 3 * VPLANE;      // [2][3 * KPLANE]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -932,12 +967,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams 
     const float* base = p.qkv + static_cast<int64_t>(b) * p.n * p.lq;
 
     if (DQ < 16) {
-        for (int i = tid; i < 2 * 3 * kNarrowPlane / 4; i += 256) reinterpret_cast<unsigned*>(&sK[0][0])[i] = 0u;
+        for (int i = tid; i < 2 * 3 * KPLANE / 4; i += 256) reinterpret_cast<unsigned*>(sK)[i] = 0u;
     }
 
     // fixed operands of this wave's 32 queries: lane (query, h) holds depth / channels 16*chunk + 8h .. + 7
-    u32x4 qf[3], dof[KCV][3];
-    load_split8(base + static_cast<int64_t>(qi) * p.lq + 8 * h, q_ok && 8 * h < DQ, qf[0], qf[1], qf[2], 1.0f);
+    u32x4 qf[KQ][3], dof[KCV][3];
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq)
+        load_split8(base + static_cast<int64_t>(qi) * p.lq + 16 * kq + 8 * h, q_ok && 16 * kq + 8 * h < DQ, qf[kq][0], qf[kq][1], qf[kq][2],
+                    1.0f);
 #pragma unroll
     for (int kc = 0; kc < KCV; ++kc)
         load_split8(p.dy + (static_cast<int64_t>(b) * p.n + qi) * p.ldd + 16 * kc + 8 * h, q_ok, dof[kc][0], dof[kc][1], dof[kc][2], g);
@@ -968,18 +1006,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams 
     auto store_tile = [&](int buf) {
         if (tid < KF4) {
             const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
-            split4_store(kreg, &sK[buf][row * 32 + c4 * 8], kNarrowPlane);
+            split4_store(kreg, sK + buf * 3 * KPLANE + row * KROW + c4 * 8, KPLANE);
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CT / 4), c4 = f % (CT / 4);
-            split4_store(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE);
+            split4_store(vreg[i], sV + buf * 3 * VPLANE + row * VROW + c4 * 8, VPLANE);
         }
     };
 
-    const int tq = (lane & 15) >> 2, tp = lane & 3;
-    const int ktr = (4 * h + tq) * 32 + tp * 8;   // K tile transposed read: rows = keys 4h + tq (+8, +16 per chunk), 16 depth columns
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    // K tile transposed read: rows = keys 4h + tq (+8, +16 per chunk), depth columns 16 * tg + 4 * tp ..
+    const int ktr = (4 * h + tq) * KROW + tp * 8 + (KD > 16 ? tg * 32 : 0);
 
     const int ktiles = (p.n + 31) / 32;
     load_tile(0);
@@ -991,8 +1030,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams 
         const bool more = t + 1 < ktiles;
         if (more) load_tile(j0 + 32);
         if (wave_active) {
-            const unsigned char* k = sK[buf];
-            const unsigned char* v = sV[buf];
+            const unsigned char* k = sK + buf * 3 * KPLANE;
+            const unsigned char* v = sV + buf * 3 * VPLANE;
             f32x16 s, dp;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
@@ -1002,11 +1041,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams 
                 for (int kk = 0; kk < 6; ++kk)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[kk]], __builtin_bit_cast(bf16x8, bb[pb[kk]]), acc, 0, 0, 0);
             };
-            {   // S^T = K Q^T: rows = keys (this tile), columns = queries (lanes)
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) {   // S^T = K Q^T: rows = keys (this tile), columns = queries (lanes)
                 bf16x8 a[3];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(k + pl * kNarrowPlane + r * 32 + h * 16);
-                six(s, a, qf);
+                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(k + pl * KPLANE + r * KROW + kq * 32 + h * 16);
+                six(s, a, qf[kq]);
             }
 #pragma unroll
             for (int kc = 0; kc < KCV; ++kc) {   // dP^T = V dO^T
@@ -1033,8 +1073,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams 
                 bf16x8 a[3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    const unsigned char* pb = k + pl * kNarrowPlane + 16 * ck * 32 + ktr;
-                    a[pl] = tr_pair(pb, pb + 8 * 32);
+                    const unsigned char* pb = k + pl * KPLANE + 16 * ck * KROW + ktr;
+                    a[pl] = tr_pair(pb, pb + 8 * KROW);
                 }
                 six(dq, a, ds[ck]);
             }
@@ -1054,13 +1094,43 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams 
 }
 
 template <int DQ, int CT>
+constexpr int dq_x3_lds() {
+    constexpr int KD = DQ < 16 ? 16 : DQ;
+    return 2 * 3 * 32 * (CT * 2 + 16) + 2 * 3 * 32 * 2 * KD;
+}
+
+template <typename K>
+bool allow_lds(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+}
+
+// split-bf16 backward for the layers whose operands fit the register file: C <= 128 in two launches
+// (dK + dV, dQ), C = 256 in three (dK, dV per 128 channels, dQ).
+template <int DQ, int C>
+int launch_bwd_x3(const BwdParams& p, int batch, hipStream_t s) {
+    const int bn = (p.n + 127) / 128;
+    if constexpr (C <= 128) {
+        constexpr int lds = dkv_x3_lds<DQ, C, true, true>();
+        if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, true>, lds)) return ddpm::fail_invalid("LDS size for attention backward (dkv)");
+        attn_bwd_dkv_x3_kernel<DQ, C, true, true><<<dim3(bn, 1, batch), 256, lds, s>>>(p);
+    } else {
+        constexpr int CV = C > 128 ? 128 : C;
+        constexpr int lds_k = dkv_x3_lds<DQ, C, true, false>(), lds_v = dkv_x3_lds<DQ, CV, false, true>();
+        if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, false>, lds_k) || !allow_lds(attn_bwd_dkv_x3_kernel<DQ, CV, false, true>, lds_v))
+            return ddpm::fail_invalid("LDS size for attention backward (dk, dv)");
+        attn_bwd_dkv_x3_kernel<DQ, C, true, false><<<dim3(bn, 1, batch), 256, lds_k, s>>>(p);
+        attn_bwd_dkv_x3_kernel<DQ, CV, false, true><<<dim3(bn, C / CV, batch), 256, lds_v, s>>>(p);
+    }
+    constexpr int lds_q = dq_x3_lds<DQ, C>();
+    if (!allow_lds(attn_bwd_dq_x3_kernel<DQ, C>, lds_q)) return ddpm::fail_invalid("LDS size for attention backward (dq)");
+    attn_bwd_dq_x3_kernel<DQ, C><<<dim3(bn, 1, batch), 256, lds_q, s>>>(p);
+    return ddpm::check_launch("attn_bwd_x3");
+}
+
+template <int DQ, int CT>
 int launch_bwd_fast(const BwdParams& p, int batch, hipStream_t s) {
     const dim3 grid((p.n + 127) / 128, 1, batch);
-    if (ddpm::split_math()) {
-        attn_bwd_dkv_x3_kernel<DQ, CT><<<grid, 256, 0, s>>>(p);
-        attn_bwd_dq_x3_kernel<DQ, CT><<<grid, 256, 0, s>>>(p);
-        return ddpm::check_launch("attn_bwd_x3");
-    }
+    if (ddpm::split_math()) return launch_bwd_x3<DQ, CT>(p, batch, s);
 #ifndef DDPM_DKV_WPS
 #define DDPM_DKV_WPS 1
 #endif
@@ -1125,6 +1195,7 @@ extern "C" int ddpm_attention_bwd(const float* qkv, const float* dy, int ldd, co
     p.ldd = ldd;
     if (c == 64 && dq == 8) return launch_bwd_fast<8, 64>(p, batch, s);
     if (c == 128 && dq == 16) return launch_bwd_fast<16, 128>(p, batch, s);
+    if (c == 256 && dq == 32 && ddpm::split_math()) return launch_bwd_x3<32, 256>(p, batch, s);
     switch (dq) {
         case 8: return launch_bwd<8>(p, batch, s);
         case 16: return launch_bwd<16>(p, batch, s);

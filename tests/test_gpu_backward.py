@@ -269,7 +269,7 @@ def test_time_embed_fwd_bwd(n_labels):
         assert_close(dtab.cpu(), table.grad, 1e-5, "d label table")
 
 
-@pytest.mark.parametrize("case", [(2, 49, 64, 8), (2, 196, 32, 4), (1, 784, 128, 16), (2, 64, 512, 64), (2, 100, 8, 1), (3, 33, 256, 32),
+@pytest.mark.parametrize("case", [(2, 49, 64, 8), (2, 196, 32, 4), (1, 784, 128, 16), (2, 64, 512, 64), (2, 100, 8, 1), (3, 33, 256, 32), (2, 196, 256, 32),
                                   (1, 1024, 128, 16)])
 def test_attention_bwd(case):
     B, N, c, dq = case
