@@ -36,6 +36,7 @@ struct WgradParams {
     int off_y, off_x, taps;
     int k_total, k_chunk, splits;
     int m_tiles, n_tiles;
+    int work;                 // workgroups with work (the grid is rounded up to a multiple of 8)
 };
 
 constexpr unsigned OOB = 0x80000000u;  // offsets at or beyond the buffer descriptor's range read as zero
@@ -57,7 +58,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     __shared__ __attribute__((aligned(16))) float sA[2][BKP * BT];
     __shared__ __attribute__((aligned(16))) float sB[2][BKP * BT];
 
-    int id = blockIdx.x;
+    // Workgroups are handed to the 8 XCDs round-robin and each XCD has its own L2: renumber so that an
+    // XCD runs CONSECUTIVE work items, i.e. the taps and channel tiles that read the same pixels share
+    // one L2 instead of each fetching its own copy over the fabric.
+    int id = static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    if (id >= p.work) return;
     const int nt = id % p.n_tiles; id /= p.n_tiles;
     const int mt = id % p.m_tiles; id /= p.m_tiles;
     const int tap = id % p.taps;
@@ -251,7 +256,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
     __shared__ __attribute__((aligned(16))) unsigned char sA[2][3 * XPLANE];
     __shared__ __attribute__((aligned(16))) unsigned char sB[2][3 * XPLANE];
 
-    int id = blockIdx.x;
+    // Workgroups are handed to the 8 XCDs round-robin and each XCD has its own L2: renumber so that an
+    // XCD runs CONSECUTIVE work items, i.e. the taps and channel tiles that read the same pixels share
+    // one L2 instead of each fetching its own copy over the fabric.
+    int id = static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    if (id >= p.work) return;
     const int nt = id % p.n_tiles; id /= p.n_tiles;
     const int mt = id % p.m_tiles; id /= p.m_tiles;
     const int tap = id % p.taps;
@@ -303,45 +312,49 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
                 master[i][j][e] = 0.f;
             }
 
-    f32x4 areg[LPT], breg[LPT];
-    auto load_global = [&](int k0) {   // must be called with k0 = k_begin, k_begin + XKP, ... in order
+    // Two register sets: the loads of step s + 2 are in flight while step s + 1 is split into LDS and
+    // step s is multiplied, so a global load has a whole step to arrive. Pixels past the chunk read
+    // as zero (out-of-range buffer offsets), which lets the loop run an even number of branch-free steps.
+    f32x4 areg[2][LPT], breg[2][LPT];
+    const int w_is_1 = p.w == 1 ? -1 : 0;
+    const unsigned inv_w1 = p.w == 1 ? 0u : inv_w;
+    const unsigned inv_per = per == 1 ? 0u : static_cast<unsigned>((0x100000000ull + per - 1) / per);
+    const int per_is_1 = per == 1 ? -1 : 0;
+    auto load_global = [&](int set, int k0) {   // must be called with k0 = k_begin, k_begin + XKP, ... in order
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int pk = k0 + row0 + RSTEP * i;
             const int rem = rrem[i], bi = rb[i];
-            const int y = p.w == 1 ? rem : static_cast<int>(__umulhi(static_cast<unsigned>(rem), inv_w));
+            const int y = static_cast<int>(__umulhi(static_cast<unsigned>(rem), inv_w1)) + (rem & w_is_1);
             const int x = rem - y * p.w;
             const bool in_chunk = pk < k_end;
             unsigned oa, ob;
             if (MODE == WG_CONVT) {
                 const int oy = 2 * y + (tap >> 1) + p.off_y, ox = 2 * x + (tap & 1) + p.off_x;
-                const bool ok = in_chunk && oy >= 0 && oy < p.a_h && ox >= 0 && ox < p.a_w;
+                const bool ok = in_chunk & (static_cast<unsigned>(oy) < static_cast<unsigned>(p.a_h)) & (static_cast<unsigned>(ox) < static_cast<unsigned>(p.a_w));
                 oa = ok ? static_cast<unsigned>((bi * p.a_h + oy) * p.a_w + ox) * p.lda * 4u + ca : OOB;
                 ob = in_chunk ? static_cast<unsigned>(pk - base_i) * p.ldb * 4u + cb : OOB;
             } else {
                 oa = in_chunk ? static_cast<unsigned>(pk - base_i) * p.lda * 4u + ca : OOB;
                 const int yy = y + dy, xx = x + dx;
-                const bool ok = in_chunk && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
+                const bool ok = in_chunk & (static_cast<unsigned>(yy) < static_cast<unsigned>(p.h)) & (static_cast<unsigned>(xx) < static_cast<unsigned>(p.w));
                 ob = ok ? static_cast<unsigned>(pk - base_i + dy * p.w + dx) * p.ldb * 4u + cb : OOB;
             }
-            areg[i] = buf_load(rs_a, oa);
-            breg[i] = buf_load(rs_b, ob);
-            int nr = rem + XKP;
-            int nb = bi;
-            while (nr >= per) {
-                nr -= per;
-                ++nb;
-            }
-            rrem[i] = nr;
-            rb[i] = nb;
+            areg[set][i] = buf_load(rs_a, oa);
+            breg[set][i] = buf_load(rs_b, ob);
+            // advance by XKP pixels: images crossed = (rem + XKP) / per, exact for these small numerators
+            const int nr = rem + XKP;
+            const int q = static_cast<int>(__umulhi(static_cast<unsigned>(nr), inv_per)) + (nr & per_is_1);
+            rrem[i] = nr - q * per;
+            rb[i] = bi + q;
         }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int set, int buf) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int off = (row0 + RSTEP * i) * XROWB + c4 * 8;
-            split4_store(areg[i], &sA[buf][off]);
-            split4_store(breg[i], &sB[buf][off]);
+            split4_store(areg[set][i], &sA[buf][off]);
+            split4_store(breg[set][i], &sB[buf][off]);
         }
     };
 
@@ -355,48 +368,97 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 
+    // One K-step from LDS buffer `set`: multiply it, split step + 1 (register set set ^ 1) into the other
+    // buffer, start the loads of step + 2 into register set `set`. The splitting arithmetic is cut into
+    // twelve stages of about eight instructions and one stage follows every other matrix instruction,
+    // so that it issues while the matrix pipe works; the scheduling barriers keep that order.
+    auto step = [&](int set, int s) {
+        const unsigned char* tA = sA[set];
+        const unsigned char* tB = sB[set];
+        bf16x8 a[2][3], b[2][3];
+        auto reads = [&](int pa, int pb) {
+            a[0][pa] = frag(tA, wm * 2, pa);
+            a[1][pa] = frag(tA, wm * 2 + 1, pa);
+            b[0][pb] = frag(tB, wn * 2, pb);
+            b[1][pb] = frag(tB, wn * 2 + 1, pb);
+        };
+        // split state of the four float4 of step + 1 (two of each operand)
+        unsigned u[4][4], m[4][4], l[4][4];
+        float r1[4][4];
+        auto src = [&](int v) -> f32x4 { return v < 2 ? areg[set ^ 1][v] : breg[set ^ 1][v - 2]; };
+        auto stage = [&](int st) {
+            const int v = st / 3, ph = st % 3;
+            if (ph == 0) {
+                const f32x4 x = src(v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u[v][e] = __float_as_uint(x[e]);
+                    r1[v][e] = x[e] - __uint_as_float(u[v][e] & 0xffff0000u);
+                }
+            } else if (ph == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    m[v][e] = __float_as_uint(r1[v][e]);
+                    l[v][e] = __float_as_uint(r1[v][e] - __uint_as_float(m[v][e] & 0xffff0000u));
+                }
+            } else {
+                u32x2 hi, mid, lo;
+                hi[0] = __builtin_amdgcn_perm(u[v][1], u[v][0], 0x07060302u);
+                hi[1] = __builtin_amdgcn_perm(u[v][3], u[v][2], 0x07060302u);
+                mid[0] = __builtin_amdgcn_perm(m[v][1], m[v][0], 0x07060302u);
+                mid[1] = __builtin_amdgcn_perm(m[v][3], m[v][2], 0x07060302u);
+                lo[0] = __builtin_amdgcn_perm(l[v][1], l[v][0], 0x07060302u);
+                lo[1] = __builtin_amdgcn_perm(l[v][3], l[v][2], 0x07060302u);
+                unsigned char* dst = (v < 2 ? &sA[set ^ 1][0] : &sB[set ^ 1][0]) + (row0 + RSTEP * (v & 1)) * XROWB + c4 * 8;
+                *reinterpret_cast<u32x2*>(dst) = hi;
+                *reinterpret_cast<u32x2*>(dst + XPLANE) = mid;
+                *reinterpret_cast<u32x2*>(dst + 2 * XPLANE) = lo;
+            }
+        };
+        auto mfma = [&](int k) {
+            const int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+            const int t = k >> 2, i = (k >> 1) & 1, j = k & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa[t]], b[j][pb[t]], acc[i][j], 0, 0, 0);
+        };
+#ifndef DDPM_WG_ABLATE
+#define DDPM_WG_ABLATE 0   // diagnostic builds only: 1 no split stages, 2 no global loads, 4 no barrier, 8 no matrix ops
+#endif
+        reads(2, 0);
+        reads(0, 2);
+        reads(1, 1);
+        if (!(DDPM_WG_ABLATE & 2)) load_global(set, k_begin + (s + 2) * XKP);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            if (!(DDPM_WG_ABLATE & 8) || p.taps == 77) mfma(k);
+            else acc[(k >> 1) & 1][k & 1][k & 15] += static_cast<float>(a[(k >> 1) & 1][k % 3][0]) + static_cast<float>(b[k & 1][k % 3][1]);
+            if ((k & 1) && (!(DDPM_WG_ABLATE & 1) || p.taps == 77)) stage(k >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!(DDPM_WG_ABLATE & 4)) __syncthreads();
+    };
+
     const int steps = (k_end - k_begin + XKP - 1) / XKP;
     if (steps > 0) {
-        load_global(k_begin);
-        store_lds(0);
+        load_global(0, k_begin);
+        store_lds(0, 0);
+        load_global(1, k_begin + XKP);
     }
     __syncthreads();
-    for (int s = 0; s < steps; ++s) {
-        const int buf = s & 1;
-        const bool more = s + 1 < steps;
-        if (more) load_global(k_begin + (s + 1) * XKP);
-        bf16x8 a[2][3], b[2][3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i][pl] = frag(sA[buf], wm * 2 + i, pl);
-                b[i][pl] = frag(sB[buf], wn * 2 + i, pl);
-            }
-        auto term = [&](int pa, int pb) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
-        };
-        term(2, 0);
-        term(0, 2);
-        term(1, 1);
-        if (more) store_lds(buf ^ 1);
-        term(1, 0);
-        term(0, 1);
-        term(0, 0);
-        if ((s & (XFOLD - 1)) == XFOLD - 1 || !more) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    master[i][j] += acc[i][j];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-                }
+    for (int s = 0; s < steps;) {
+        const int fold_end = min(steps, s + XFOLD);
+        for (; s < fold_end; s += 2) {   // an odd last step is followed by one of zeros
+            step(0, s);
+            step(1, s + 1);
         }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                master[i][j] += acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            }
     }
 
     float* outp = p.out + static_cast<int64_t>(tap) * p.m_total * p.n_total;
@@ -434,8 +496,9 @@ int launch_wgrad(WgradParams& p, hipStream_t s) {
     splits = (p.k_total + chunk - 1) / chunk;
     p.k_chunk = static_cast<int>(chunk);
     p.splits = static_cast<int>(splits);
-    const int64_t grid = tiles * splits;
-    if (grid > 0x7fffffffll) return ddpm::fail_invalid("wgrad grid size");
+    if (tiles * splits > 0x7ffffff0ll) return ddpm::fail_invalid("wgrad grid size");
+    p.work = static_cast<int>(tiles * splits);
+    const int64_t grid = (tiles * splits + 7) / 8 * 8;
     hipError_t e = hipMemsetAsync(p.out, 0, sizeof(float) * static_cast<size_t>(p.taps) * p.m_total * p.n_total, s);
     if (e != hipSuccess) {
         ddpm::set_error("hipMemsetAsync: %s", hipGetErrorString(e));
