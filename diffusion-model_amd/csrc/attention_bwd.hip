@@ -716,8 +716,8 @@ __device__ __forceinline__ int swz(int row, int ch) { return 256 * row + 16 * (c
 // starting at blockIdx.y * CT (CT <= 128; the dO tile is read transposed and sits in swizzled 256-byte
 // rows). Both at once when the registers allow (C <= 128); wider layers run the two halves as separate
 // launches, each recomputing the scores (depth-DQ products, cheap beside the C-deep ones).
-template <int DQ, int CT, bool DK, bool DV>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_x3_kernel(const BwdParams p) {
+template <int DQ, int CT, bool DK, bool DV, int WPS = 1>
+__global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdParams p) {
     static_assert(!DV || CT <= 128, "transposed dO reads assume 256-byte rows");
     constexpr int NCT = CT / 32, KCV = CT / 16;
     constexpr int KD = DQ < 16 ? 16 : DQ, KQ = KD / 16;   // padded depth, 16-deep chunks of it
@@ -1109,17 +1109,27 @@ bool allow_lds(K kernel, int bytes) {
 template <int DQ, int C>
 int launch_bwd_x3(const BwdParams& p, int batch, hipStream_t s) {
     const int bn = (p.n + 127) / 128;
-    if constexpr (C <= 128) {
+#ifndef DDPM_ATTN_SPLIT128
+#define DDPM_ATTN_SPLIT128 1
+#endif
+    if constexpr (C <= 128 && !(DDPM_ATTN_SPLIT128 && C == 128)) {
         constexpr int lds = dkv_x3_lds<DQ, C, true, true>();
         if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, true>, lds)) return ddpm::fail_invalid("LDS size for attention backward (dkv)");
         attn_bwd_dkv_x3_kernel<DQ, C, true, true><<<dim3(bn, 1, batch), 256, lds, s>>>(p);
+    } else if constexpr (C == 128) {
+        // two lighter kernels that fit two waves per SIMD beat the fused one at one wave per SIMD
+        constexpr int lds_k = dkv_x3_lds<DQ, C, true, false>(), lds_v = dkv_x3_lds<DQ, C, false, true>();
+        if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, false, 2>, lds_k) || !allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, false, true, 2>, lds_v))
+            return ddpm::fail_invalid("LDS size for attention backward (dk, dv)");
+        attn_bwd_dkv_x3_kernel<DQ, C, true, false, 2><<<dim3(bn, 1, batch), 256, lds_k, s>>>(p);
+        attn_bwd_dkv_x3_kernel<DQ, C, false, true, 2><<<dim3(bn, 1, batch), 256, lds_v, s>>>(p);
     } else {
         constexpr int CV = C > 128 ? 128 : C;
         constexpr int lds_k = dkv_x3_lds<DQ, C, true, false>(), lds_v = dkv_x3_lds<DQ, CV, false, true>();
-        if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, false>, lds_k) || !allow_lds(attn_bwd_dkv_x3_kernel<DQ, CV, false, true>, lds_v))
+        if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, false>, lds_k) || !allow_lds(attn_bwd_dkv_x3_kernel<DQ, CV, false, true, 2>, lds_v))
             return ddpm::fail_invalid("LDS size for attention backward (dk, dv)");
         attn_bwd_dkv_x3_kernel<DQ, C, true, false><<<dim3(bn, 1, batch), 256, lds_k, s>>>(p);
-        attn_bwd_dkv_x3_kernel<DQ, CV, false, true><<<dim3(bn, C / CV, batch), 256, lds_v, s>>>(p);
+        attn_bwd_dkv_x3_kernel<DQ, CV, false, true, 2><<<dim3(bn, C / CV, batch), 256, lds_v, s>>>(p);
     }
     constexpr int lds_q = dq_x3_lds<DQ, C>();
     if (!allow_lds(attn_bwd_dq_x3_kernel<DQ, C>, lds_q)) return ddpm::fail_invalid("LDS size for attention backward (dq)");

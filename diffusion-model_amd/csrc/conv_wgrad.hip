@@ -292,14 +292,34 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
     const int row0 = tid / F4R, c4 = tid % F4R;
     const unsigned ca = m0 + c4 * 4 < p.m_total ? static_cast<unsigned>(m0 + c4 * 4) * 4u : OOB;
     const unsigned cb = n0 + c4 * 4 < p.n_total ? static_cast<unsigned>(n0 + c4 * 4) * 4u : OOB;
-    const unsigned inv_w = static_cast<unsigned>((0x100000000ull + p.w - 1) / p.w);
-    int rb[LPT], rrem[LPT];
+    // Per-thread walk over its pixels (one every XKP per step), kept as (x, y) inside the image plus
+    // running byte offsets, so that a step costs adds, compares and selects only: advancing XKP pixels
+    // is q16 rows and r16 columns, with one carry each into the row and the image.
+    const int r16 = XKP % p.w, q16 = XKP / p.w, ri = q16 % p.h, qi = q16 / p.h;
+    int px[LPT], py[LPT], pkv[LPT];
+    unsigned oa_run[LPT], ob_run[LPT];
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         const int pk = k_begin + row0 + RSTEP * i;
-        rb[i] = pk / per;
-        rrem[i] = pk - rb[i] * per;
+        const int bi = pk / per, rem = pk - bi * per;
+        py[i] = rem / p.w;
+        px[i] = rem - py[i] * p.w;
+        pkv[i] = pk;
+        if (MODE == WG_CONVT) {
+            const int oy = 2 * py[i] + (tap >> 1) + p.off_y, ox = 2 * px[i] + (tap & 1) + p.off_x;
+            oa_run[i] = static_cast<unsigned>((bi * p.a_h + oy) * p.a_w + ox) * p.lda * 4u + ca;
+            ob_run[i] = static_cast<unsigned>(pk - base_i) * p.ldb * 4u + cb;
+        } else {
+            oa_run[i] = static_cast<unsigned>(pk - base_i) * p.lda * 4u + ca;
+            ob_run[i] = static_cast<unsigned>(pk - base_i + dy * p.w + dx) * p.ldb * 4u + cb;
+        }
     }
+    // offset steps: the linear ones, and for the transposed conv the (2y, 2x) walk over the larger image
+    const unsigned a_step = MODE == WG_CONVT ? static_cast<unsigned>((qi * p.a_h + 2 * ri) * p.a_w + 2 * r16) * p.lda * 4u
+                                             : static_cast<unsigned>(XKP) * p.lda * 4u;
+    const unsigned a_cx = static_cast<unsigned>(2 * p.a_w - 2 * p.w) * p.lda * 4u;                    // a column carry
+    const unsigned a_cy = static_cast<unsigned>(p.a_h * p.a_w - 2 * p.h * p.a_w) * p.lda * 4u;        // a row carry
+    const unsigned b_step = static_cast<unsigned>(XKP) * p.ldb * 4u;
 
     f32x16 acc[2][2], master[2][2];
 #pragma unroll
@@ -316,37 +336,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
     // step s is multiplied, so a global load has a whole step to arrive. Pixels past the chunk read
     // as zero (out-of-range buffer offsets), which lets the loop run an even number of branch-free steps.
     f32x4 areg[2][LPT], breg[2][LPT];
-    const int w_is_1 = p.w == 1 ? -1 : 0;
-    const unsigned inv_w1 = p.w == 1 ? 0u : inv_w;
-    const unsigned inv_per = per == 1 ? 0u : static_cast<unsigned>((0x100000000ull + per - 1) / per);
-    const int per_is_1 = per == 1 ? -1 : 0;
-    auto load_global = [&](int set, int k0) {   // must be called with k0 = k_begin, k_begin + XKP, ... in order
+    auto load_global = [&](int set) {   // the n-th call loads pixels k_begin + n * XKP ...
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            const int pk = k0 + row0 + RSTEP * i;
-            const int rem = rrem[i], bi = rb[i];
-            const int y = static_cast<int>(__umulhi(static_cast<unsigned>(rem), inv_w1)) + (rem & w_is_1);
-            const int x = rem - y * p.w;
-            const bool in_chunk = pk < k_end;
-            unsigned oa, ob;
+            const int x = px[i], y = py[i];
+            const bool in_chunk = pkv[i] < k_end;
+            bool ok;
             if (MODE == WG_CONVT) {
                 const int oy = 2 * y + (tap >> 1) + p.off_y, ox = 2 * x + (tap & 1) + p.off_x;
-                const bool ok = in_chunk & (static_cast<unsigned>(oy) < static_cast<unsigned>(p.a_h)) & (static_cast<unsigned>(ox) < static_cast<unsigned>(p.a_w));
-                oa = ok ? static_cast<unsigned>((bi * p.a_h + oy) * p.a_w + ox) * p.lda * 4u + ca : OOB;
-                ob = in_chunk ? static_cast<unsigned>(pk - base_i) * p.ldb * 4u + cb : OOB;
+                ok = in_chunk & (static_cast<unsigned>(oy) < static_cast<unsigned>(p.a_h)) & (static_cast<unsigned>(ox) < static_cast<unsigned>(p.a_w));
+                areg[set][i] = buf_load(rs_a, ok ? oa_run[i] : OOB);
+                breg[set][i] = buf_load(rs_b, in_chunk ? ob_run[i] : OOB);
             } else {
-                oa = in_chunk ? static_cast<unsigned>(pk - base_i) * p.lda * 4u + ca : OOB;
                 const int yy = y + dy, xx = x + dx;
-                const bool ok = in_chunk & (static_cast<unsigned>(yy) < static_cast<unsigned>(p.h)) & (static_cast<unsigned>(xx) < static_cast<unsigned>(p.w));
-                ob = ok ? static_cast<unsigned>(pk - base_i + dy * p.w + dx) * p.ldb * 4u + cb : OOB;
+                ok = in_chunk & (static_cast<unsigned>(yy) < static_cast<unsigned>(p.h)) & (static_cast<unsigned>(xx) < static_cast<unsigned>(p.w));
+                areg[set][i] = buf_load(rs_a, in_chunk ? oa_run[i] : OOB);
+                breg[set][i] = buf_load(rs_b, ok ? ob_run[i] : OOB);
             }
-            areg[set][i] = buf_load(rs_a, oa);
-            breg[set][i] = buf_load(rs_b, ob);
-            // advance by XKP pixels: images crossed = (rem + XKP) / per, exact for these small numerators
-            const int nr = rem + XKP;
-            const int q = static_cast<int>(__umulhi(static_cast<unsigned>(nr), inv_per)) + (nr & per_is_1);
-            rrem[i] = nr - q * per;
-            rb[i] = bi + q;
+            int nx = x + r16;
+            const bool cx = nx >= p.w;
+            nx -= cx ? p.w : 0;
+            int ny = y + ri + (cx ? 1 : 0);
+            const bool cy = ny >= p.h;
+            ny -= cy ? p.h : 0;
+            px[i] = nx;
+            py[i] = ny;
+            pkv[i] += XKP;
+            ob_run[i] += b_step;
+            if (MODE == WG_CONVT) oa_run[i] += a_step + (cx ? a_cx : 0u) + (cy ? a_cy : 0u);
+            else oa_run[i] += a_step;
         }
     };
     auto store_lds = [&](int set, int buf) {
@@ -426,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
         reads(2, 0);
         reads(0, 2);
         reads(1, 1);
-        if (!(DDPM_WG_ABLATE & 2)) load_global(set, k_begin + (s + 2) * XKP);
+        if (!(DDPM_WG_ABLATE & 2)) load_global(set);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 24; ++k) {
@@ -440,9 +458,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
 
     const int steps = (k_end - k_begin + XKP - 1) / XKP;
     if (steps > 0) {
-        load_global(0, k_begin);
+        load_global(0);
         store_lds(0, 0);
-        load_global(1, k_begin + XKP);
+        load_global(1);
     }
     __syncthreads();
     for (int s = 0; s < steps;) {
