@@ -189,7 +189,10 @@ def main():
             if dist is not None:                                             # data-parallel: average gradients over ranks
                 parallel.average_gradients(params)
             opt.step()
-            state["loss"] = loss.item()
+            if os.environ.get("DDPM_BENCH_DEFER_LOSS"):                      # diagnostic: no host sync inside the step
+                state["loss_t"] = loss
+            else:
+                state["loss"] = loss.item()
 
     def barrier():
         torch.cuda.synchronize()

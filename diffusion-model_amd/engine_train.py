@@ -7,6 +7,7 @@ a plain Python structure, backward walks it in reverse and returns one gradient 
 (first-iteration/main.py:76-84) work unchanged.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -223,7 +224,8 @@ class TrainMixin:
         dgamma = torch.empty(1, device=dev, dtype=torch.float32)
         e = torch.empty((b, n), device=dev, dtype=torch.float32)
         ws = self._workspace(dev)
-        self._launch("attention_bwd", 2.0 * b * n * n * (2 * dqp + 2 * c + dqp + c), "ddpm_attention_bwd", qkv.ptr, dout.ptr, dout.ld,
+        x3 = os.environ.get("DDPM_CONV_MATH", "") != "fp32" and (c, dqp) in ((64, 8), (128, 16), (256, 32))
+        self._launch("attention_bwd<split-bf16>" if x3 else "attention_bwd<fp32>", 2.0 * b * n * n * (2 * dqp + 2 * c + dqp + c), "ddpm_attention_bwd", qkv.ptr, dout.ptr, dout.ld,
                      _ptr(rec["raw"]), _ptr(rec["lse"]), _ptr(self.T(key + ".gamma")), _ptr(ws), _ptr(e), dqkv.ptr, _ptr(dgamma), b, n, c,
                      dqp, _stream())
         grads[key + ".gamma"] = dgamma
@@ -366,10 +368,13 @@ class UNetFunction(torch.autograd.Function):
         out, fms, tape = engine.forward_train(x, t, y)
         ctx.engine, ctx.tape, ctx.names = engine, tape, names
         ctx.mark_non_differentiable(*fms)
+        ctx.set_materialize_grads(False)   # no zero-filled gradient tensors for the feature maps
         return (out, *fms)
 
     @staticmethod
     def backward(ctx, dout, *unused):
+        if dout is None:                   # nothing downstream depends on the prediction
+            return (None,) * (5 + len(ctx.names))
         grads = ctx.engine.backward(ctx.tape, dout)
         ctx.tape = None
         return (None, None, None, None, None, *[grads.get(n) for n in ctx.names])

@@ -53,3 +53,42 @@ for _ in range(3):
     step()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+
+
+def phased():
+    """One step with a CUDA event and a host timestamp at every phase boundary."""
+    names, evs, host = [], [], []
+
+    def mark(nm):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        names.append(nm), evs.append(e), host.append(time.perf_counter())
+
+    mark("start")
+    noise = torch.randn_like(data)
+    t = torch.randint(0, 1000, (B,), device=dev)
+    noisy = dm.add_noise(data, noise, t)
+    mark("noise")
+    pred = model(noisy, t)
+    mark("forward")
+    loss = crit(pred, noise)
+    opt.zero_grad()
+    mark("loss")
+    loss.backward()
+    mark("backward")
+    opt.step()
+    mark("adam")
+    v = loss.item()
+    mark("item")
+    torch.cuda.synchronize()
+    return names, evs, host, v
+
+
+for _ in range(2):
+    phased()
+print("phase      host_ms(cum)  gpu_ms(phase)")
+for rep in range(3):
+    names, evs, host, _ = phased()
+    for i in range(1, len(names)):
+        print(f"{names[i]:10s} {1e3 * (host[i] - host[0]):10.2f} {evs[i - 1].elapsed_time(evs[i]):12.2f}")
+    print(f"total gpu {evs[0].elapsed_time(evs[-1]):.2f} ms")
