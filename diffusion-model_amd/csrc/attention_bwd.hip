@@ -1112,11 +1112,11 @@ int launch_bwd_x3(const BwdParams& p, int batch, hipStream_t s) {
 #ifndef DDPM_ATTN_SPLIT128
 #define DDPM_ATTN_SPLIT128 1
 #endif
-    if constexpr (C <= 128 && !(DDPM_ATTN_SPLIT128 && C == 128)) {
+    if constexpr (C <= 128 && !DDPM_ATTN_SPLIT128) {
         constexpr int lds = dkv_x3_lds<DQ, C, true, true>();
         if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, true>, lds)) return ddpm::fail_invalid("LDS size for attention backward (dkv)");
         attn_bwd_dkv_x3_kernel<DQ, C, true, true><<<dim3(bn, 1, batch), 256, lds, s>>>(p);
-    } else if constexpr (C == 128) {
+    } else if constexpr (C <= 128) {
         // two lighter kernels that fit two waves per SIMD beat the fused one at one wave per SIMD
         constexpr int lds_k = dkv_x3_lds<DQ, C, true, false>(), lds_v = dkv_x3_lds<DQ, C, false, true>();
         if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, false, 2>, lds_k) || !allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, false, true, 2>, lds_v))

@@ -3,6 +3,7 @@
 
     python tools/microbench.py conv3x3 B H W Cin Cout [iters]
     python tools/microbench.py wgrad   B H W Cin Cout [iters]
+    python tools/microbench.py conv1x1 B H W Cin Cout [iters]
     python tools/microbench.py attn    B N C [iters]         (forward + backward)
     python tools/microbench.py step    NELEMS [iters]        (reverse-step kernel, HBM-bound)
 Prints the average launch time from HIP events and the achieved TFLOP/s or GB/s.
@@ -62,6 +63,20 @@ def main():
             packed, gw = torch.empty(w.numel(), device=dev), torch.empty_like(w)
             t = timeit(lambda: call("ddpm_conv3x3_wgrad", P(dy), co, co, P(x), ci, ci, B, H, W, P(packed), P(gw), S()), iters)
         print(f"{kind} B={B} {H}x{W} {ci}->{co}: {t*1e6:.1f} us  {flops/t/1e12:.1f} TFLOP/s")
+    elif kind == "conv1x1":
+        B, H, W, ci, co = a[:5]
+        iters = a[5] if len(a) > 5 else 20
+        x = torch.randn(B, H, W, ci, device=dev)
+        w = torch.randn(co, ci, device=dev) * ci ** -0.5
+        wp = torch.empty(packed_floats(1, co, ci), device=dev)
+        call("ddpm_pack_conv1x1", P(w), co, ci, 0, P(wp), S())
+        y = torch.empty(B, H, W, co, device=dev)
+        d = ConvDesc(batch=B, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=0, ldr=0, out_h=H, out_w=W)
+        sc, sh = torch.ones(co, device=dev), torch.zeros(co, device=dev)
+        ep = Epilogue(P(sc), P(sh), None, None)
+        t = timeit(lambda: call("ddpm_conv1x1_fwd", C.byref(d), P(x), None, P(wp), C.byref(ep), P(y), S()), iters)
+        gb = 4.0 * B * H * W * (ci + co)
+        print(f"conv1x1 B={B} {H}x{W} {ci}->{co}: {t*1e6:.1f} us  {2.0*B*H*W*ci*co/t/1e12:.1f} TFLOP/s  {gb/t/1e12:.2f} TB/s algorithmic")
     elif kind == "attn":
         B, N, c = a[:3]
         iters = a[3] if len(a) > 3 else 10
