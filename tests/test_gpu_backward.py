@@ -93,7 +93,8 @@ def pack3(w, flip):
 
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 8, 16), (3, 28, 28, 64, 64), (2, 14, 14, 128, 256), (6, 7, 7, 512, 256), (2, 30, 30, 32, 8),
-                                  (16, 28, 28, 64, 128)])
+                                  (16, 28, 28, 64, 128), (6, 3, 3, 512, 512), (40, 1, 1, 128, 128), (3, 5, 3, 128, 96), (2, 2, 17, 72, 136),
+                                  (5, 33, 1, 128, 64)])
 def test_conv3x3_dgrad_wgrad(case):
     B, H, W, ci, co = case
     x = rnd((B, ci, H, W), 1).requires_grad_(True)
@@ -133,7 +134,8 @@ def test_conv1x1_bwd(case):
 
 
 @pytest.mark.parametrize("case", [(2, 7, 7, 64, 32, 14, 14), (2, 7, 7, 32, 16, 15, 15), (2, 16, 16, 32, 16, 16, 16),
-                                  (3, 14, 14, 128, 64, 28, 28), (2, 7, 5, 16, 8, 17, 9)])
+                                  (3, 14, 14, 128, 64, 28, 28), (2, 7, 5, 16, 8, 17, 9), (2, 7, 7, 128, 128, 13, 13), (9, 1, 1, 256, 128, 3, 3),
+                                  (4, 3, 3, 512, 256, 7, 7)])
 def test_convT_bwd(case):
     B, H, W, ci, co, OH, OW = case
     x = rnd((B, ci, H, W), 1).requires_grad_(True)
