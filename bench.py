@@ -49,6 +49,13 @@ WORKLOADS = {
     "sample": dict(name="configs[2]: third-iteration UNet (1,1,64,128,num_classes=10), 1x32x32, full T=1000 ancestral sampling, "
                         "batch 4096 sharded over 8 GPUs (512 per GPU)", variant=3, cin=1, hw=32, batch=512, labels=True,
                    metric="sampled images/sec (full T-step loop)", unit="images/s"),
+    # the remaining configs: parity-test shapes, measurable here on request (never the default line)
+    "train_color": dict(name="configs[3]: third-iteration UNet (3,3,64,128), colour 3x32x32, batch 256 per GPU training step, "
+                             "data-parallel gradient all-reduce", variant=3, cin=3, hw=32, batch=256, labels=False,
+                        metric="train samples/sec", unit="samples/s"),
+    "sample_64": dict(name="configs[4]: third-iteration UNet (3,3,64,128), 3x64x64 (attention at N=4096, 1024, 256), full T=1000 "
+                           "ancestral sampling, batch 8192 sharded over 8 GPUs (1024 per GPU)", variant=3, cin=3, hw=64, batch=1024,
+                      labels=False, metric="sampled images/sec (full T-step loop)", unit="images/s"),
 }
 
 
@@ -71,7 +78,7 @@ def cpu_baseline(workload, wl, seconds=12.0):
     alphas, abar = O.schedule_tables(betas)
     B, cin, hw = 8, wl["cin"], wl["hw"]
     n, t0 = 0, time.time()
-    if workload == "sample":
+    if workload.startswith("sample"):
         x = torch.randn(B, cin, hw, hw)
         t = torch.full((B,), 500, dtype=torch.long)
         y = torch.tensor([3]) if wl["labels"] else None
@@ -151,7 +158,7 @@ def main():
     dm = pkg.make_diffusion_class(wl["variant"])(model, betas, T_FULL)
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
 
-    if args.workload == "sample":
+    if args.workload.startswith("sample"):
         model.eval()
         labels = torch.tensor([3], device=dev) if wl["labels"] else None
         state = {"x": torch.randn(shape, generator=gen).to(dev), "t": T_FULL - 1}
@@ -244,7 +251,7 @@ def main():
     if world == 1:
         prof = model._engine.prof
         model._engine.prof = None
-    if args.workload == "sample":
+    if args.workload.startswith("sample"):
         assert torch.isfinite(state["x"]).all()
     else:
         assert state["loss"] == state["loss"], "loss is NaN"
@@ -254,7 +261,7 @@ def main():
         dt = tt.item()
     sec_per_step = dt / args.steps
     total_b = B * world
-    value = total_b / (T_FULL * sec_per_step) if args.workload == "sample" else total_b / sec_per_step
+    value = total_b / (T_FULL * sec_per_step) if args.workload.startswith("sample") else total_b / sec_per_step
 
     # per-kernel figures from the HIP events recorded around every MFMA launch of the timed steps
     agg = {}
@@ -273,7 +280,7 @@ def main():
                        peak_tflops=round(kernel_peak(k), 1), frac=round(v[0] / v[1] / 1e12 / kernel_peak(k), 4),
                        share_of_step=round(v[1] / prof_steps / sec_per_step, 3)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
     cfg = {"workload": wl["name"], "per_gpu_batch": B, "global_batch": total_b}
-    if args.workload == "sample":
+    if args.workload.startswith("sample"):
         cfg.update(T=T_FULL, step="one denoising step (UNet eval forward + noise draw + fused reverse-step kernel); "
                                   "images/s = global_batch / (T * seconds_per_step)")
     else:
