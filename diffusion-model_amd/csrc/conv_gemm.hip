@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
                     } else {
                         const int64_t pix = info.x;
                         if (p.residual) v += p.residual[pix * p.ldr + n];
-                        v = apply_act(v, p.act);
+                        v = apply_act_fast(v, p.act);
                         if (p.temb) v += p.temb[static_cast<int64_t>(info.y) * p.cout + n];
                         p.out[pix * p.ldo + n] = v;
                     }
