@@ -31,7 +31,8 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # gfx950 dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 BF16_MFMA_PEAK_TFLOPS = 2516.6    # gfx950 dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
-SPLIT_PRODUCTS = 6                # bf16 MFMA products per fp32 product in the split-bf16 kernels
+SPLIT_PRODUCTS = 6
+SUSTAINED_BF16_TFLOPS = 1900.0    # measured: pure-MFMA loop, two waves per SIMD (tools/probe/mfma_power.hip)                # bf16 MFMA products per fp32 product in the split-bf16 kernels
 
 
 def kernel_peak(label):
@@ -295,6 +296,9 @@ def main():
         "config": cfg,
         "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(kernel_peak(dom[0]), 1),
                      "unit": "TFLOP/s", "frac": round(achieved / kernel_peak(dom[0]), 4), "traffic": None,
+                     "sustained_peak": (SUSTAINED_BF16_TFLOPS / SPLIT_PRODUCTS if "split-bf16" in dom[0] else None),
+                     "sustained_peak_note": "a loop of nothing but independent v_mfma_f32_32x32x16_bf16 (tools/probe/mfma_power.hip) "
+                                            "sustains 1.9 PFLOP/s on this chip (1.8 GHz under that load, not the 2.4 GHz of the nominal peak)",
                      "arithmetic": ("fp32 operands split exactly into 3 bf16 terms, 6 cross products per fp32 product on "
                                     "v_mfma_f32_32x32x16_bf16 with fp32 accumulation: achieved/peak count algorithmic fp32 FLOP, "
                                     "peak = bf16 dense peak / 6" if "split-bf16" in dom[0] else "v_mfma_f32_32x32x2_f32"),
