@@ -12,6 +12,7 @@
 // adds its partial tile into the packed result [tap][M][N] with fp32 atomics (contiguous along n),
 // which the caller has zeroed. A second tiny kernel permutes the packed result into torch's
 // parameter layout.
+#include <cstdlib>
 #include "common.h"
 
 using ddpm::as_stream;
@@ -505,7 +506,11 @@ int launch_wgrad(WgradParams& p, hipStream_t s) {
     // workgroups per CU (64 KB of LDS each), the 64-wide one 4: aim at two rounds of the resident
     // capacity and never exceed it by a few stragglers, which would cost a whole extra round.
     const int64_t slots = 256 * (big ? 2 : 4);
-    int64_t splits = (2 * slots) / tiles;
+    static const int rounds = [] {   // diagnostic override of the number of resident rounds the splits aim at
+        const char* e = getenv("DDPM_WGRAD_ROUNDS");
+        return e ? atoi(e) : 2;
+    }();
+    int64_t splits = (rounds * slots) / tiles;
     const int64_t max_splits = (p.k_total + 255) / 256;      // at least 8 K-steps per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
