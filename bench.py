@@ -131,6 +131,9 @@ def main():
                     help="bracket every N-th MFMA launch of the timed steps with HIP events (1 = all; events cost GPU time)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--settle", type=float, default=1.5, help="seconds of untimed steps before the warm-up steps")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the multi-GPU code path (process group, collectives) "
+                                                              "even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,6 +146,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    multi = world > 1 or args.force_dist
     log(f"world={world} device={dev} workload={args.workload}")
     if os.environ.get("DDPM_BENCH_TRACE"):
         import faulthandler
@@ -194,8 +198,16 @@ def main():
             loss = crit(pred, noise)
             opt.zero_grad()
             loss.backward()
-            if dist is not None:                                             # data-parallel: average gradients over ranks
+            if dist is not None and not os.environ.get("DDPM_BENCH_SKIP_ALLREDUCE"):   # data-parallel: average gradients over ranks
                 parallel.average_gradients(params)
+            elif os.environ.get("DDPM_BENCH_FLAT_GRADS"):                    # diagnostic: gradients as views of one buffer
+                gs = [p for p in params if p.grad is not None]
+                flat = torch.cat([p.grad.reshape(-1) for p in gs])
+                off = 0
+                for p in gs:
+                    n = p.grad.numel()
+                    p.grad = flat[off:off + n].view_as(p.grad)
+                    off += n
             opt.step()
             if os.environ.get("DDPM_BENCH_DEFER_LOSS"):                      # diagnostic: no host sync inside the step
                 state["loss_t"] = loss
@@ -214,7 +226,7 @@ def main():
             log(f"rank {rank}: left barrier", True)
 
     prof = None
-    if world > 1:
+    if multi:
         # Per-kernel HIP events are taken in a pre-pass BEFORE the process group exists (2 steps, no
         # collective), so that event recording never interleaves with RCCL traffic in the timed region.
         log("multi-GPU: profiling pre-pass (no collectives)")
@@ -227,18 +239,32 @@ def main():
         model._engine.prof = None
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if os.environ.get("DDPM_BENCH_NO_PG"):      # diagnostic: the multi-GPU control flow without a process group
+            dist_mod = None
+        elif args.backend == "nccl":
             dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist_mod.init_process_group(args.backend, rank=rank, world_size=world)
         dist = dist_mod
-        parallel.broadcast_parameters(model)
+        if dist is not None:
+            parallel.broadcast_parameters(model)
 
-    log("model built; warm-up")
+    # Settling steps before the W warm-up steps: the first second of a process holds one-off host stalls
+    # (first-use initialisation inside the HIP runtime and the caching allocator: a single step of the first
+    # dozen takes 50-80 ms instead of 29), which would otherwise land inside a short timed region.
+    log("model built; settling")
+    t_settle = time.perf_counter() + args.settle
+    n_settle = 0
+    while time.perf_counter() < t_settle:
+        one_step()
+        n_settle += 1
+    torch.cuda.synchronize()
+    log(f"{n_settle} settling steps; warm-up")
     for _ in range(args.warmup):
         one_step()
     log("timed steps")
-    if world == 1:
+    if not multi:
         model._engine.prof = []
         model._engine.prof_stride = max(1, args.profile_stride)
     barrier()
@@ -249,7 +275,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     log(f"done: {dt / args.steps * 1e3:.2f} ms/step on this rank")
-    if world == 1:
+    if not multi:
         prof = model._engine.prof
         model._engine.prof = None
     if args.workload.startswith("sample"):
@@ -272,11 +298,11 @@ def main():
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
     if not agg:
-        sys.exit("no MFMA launch was sampled: lower --profile-stride")
+        sys.exit(f"no MFMA launch was sampled: lower --profile-stride ({sec_per_step * 1e3:.3f} ms/step)")
     dom = max(agg.items(), key=lambda kv: kv[1][1])
     achieved = dom[1][0] / dom[1][1] / 1e12
     # launches are sampled 1 in `stride` (all of them in the multi-GPU pre-pass): scale the summed time back up
-    prof_steps = args.steps / max(1, args.profile_stride) if world == 1 else 2
+    prof_steps = args.steps / max(1, args.profile_stride) if not multi else 2
     kernels = {k: dict(sampled_launches=v[2], avg_ms=round(v[1] / v[2] * 1e3, 4), tflops=round(v[0] / v[1] / 1e12, 2),
                        peak_tflops=round(kernel_peak(k), 1), frac=round(v[0] / v[1] / 1e12 / kernel_peak(k), 4),
                        share_of_step=round(v[1] / prof_steps / sec_per_step, 3)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
@@ -287,7 +313,7 @@ def main():
     else:
         cfg.update(optimizer="torch.optim.Adam(lr=2e-4)", batchnorm="per-rank batch statistics",
                    parallelism=("dp%d: %s all-reduce of flattened gradients" % (world, "RCCL" if args.backend == "nccl" else args.backend))
-                   if world > 1 else "single GPU",
+                   if multi else "single GPU",
                    last_loss=round(state["loss"], 5))
     out = {
         "metric": wl["metric"], "value": round(value, 4), "unit": wl["unit"],
@@ -303,12 +329,12 @@ def main():
                                     "v_mfma_f32_32x32x16_bf16 with fp32 accumulation: achieved/peak count algorithmic fp32 FLOP, "
                                     "peak = bf16 dense peak / 6" if "split-bf16" in dom[0] else "v_mfma_f32_32x32x2_f32"),
                      "avg_launch_ms": round(dom[1][1] / dom[1][2] * 1e3, 4), "sampled_launches": dom[1][2],
-                     "measured": f"HIP events around every {max(1, args.profile_stride)}-th MFMA launch of the timed steps (rotating over the launch sites)" if world == 1 else
+                     "measured": f"HIP events around every {max(1, args.profile_stride)}-th MFMA launch of the timed steps (rotating over the launch sites)" if not multi else
                                  "HIP events in a 2-step pre-pass before the process group is created"},
         "kernels": kernels,
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, wl)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -42,8 +42,7 @@ def all_reduce_(t, op=None, group=None):
 
 def broadcast_parameters(module, src=0, group=None):
     """Make every rank start from rank `src`'s parameters and buffers."""
-    world, _ = _world(group)
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         if t.is_cuda and _host_staged(group):
@@ -58,9 +57,11 @@ def average_gradients(params, group=None):
     """All-reduce (mean) of the gradients of `params`: one collective over the flattened buffer
     (4 bytes per parameter: 31-50 MB for the three UNets). Afterwards every `.grad` is a view into
     that buffer, so nothing is copied back (one concatenation, one collective, one scale per step)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
     world, _ = _world(group)
     with_grad = [p for p in params if p.grad is not None]
-    if world == 1 or not with_grad:
+    if not with_grad:
         return
     flat = torch.cat([p.grad.reshape(-1) for p in with_grad])
     all_reduce_(flat, group=group)
