@@ -6,6 +6,7 @@ a plain Python structure, backward walks it in reverse and returns one gradient 
 `loss.backward()` / `optim.Adam.step()` of the reference's training loop
 (first-iteration/main.py:76-84) work unchanged.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -26,6 +27,9 @@ def _stream():
 
 
 class TrainMixin:
+    _s2 = None                                                      # second stream of the backward pass (weight gradients)
+    _use_side = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # diagnostic switch: "0" keeps the backward on one stream
+
     # ------------------------------------------------------------------ scratch
     def _workspace(self, dev):
         ws = getattr(self, "_ws", None)
@@ -168,6 +172,22 @@ class TrainMixin:
         return out, [f.nchw() for f in fms], tape
 
     # ------------------------------------------------------------------ backward pieces
+    def _side(self, *tensors):
+        """Context in which launches go to a second stream that first waits for everything issued so far on
+        the current one. Weight gradients have no consumer before the optimizer step, so they run there,
+        beside the chain of data gradients (which is a string of short reduction/packing kernels between
+        the large ones). `tensors` are marked as used by that stream, so that the caching allocator does not
+        hand their memory out again before the side stream is done with it. backward() joins the streams."""
+        if not self._use_side:
+            return contextlib.nullcontext()
+        main = torch.cuda.current_stream()
+        if self._s2 is None:
+            self._s2 = torch.cuda.Stream(device=main.device)
+        self._s2.wait_stream(main)
+        for t in tensors:
+            t.record_stream(self._s2)
+        return torch.cuda.stream(self._s2)
+
     def _conv_bn_bwd(self, V, rec, dout, grads, add=None, need_dsrc=True):
         """dout: View, gradient of the block's output. Returns the gradient w.r.t. rec['src'] (a View)
         and the gradient w.r.t. the residual input (a View or None)."""
@@ -195,8 +215,9 @@ class TrainMixin:
             return None, dres
         src = rec["src"]
         packed = torch.empty(wt.numel(), device=dev, dtype=torch.float32)
-        self._launch(self._wgrad_label("conv3x3", cout, src.c), 2.0 * rows * cout * 9 * src.c, "ddpm_conv3x3_wgrad", draw.ptr, draw.ld, cout, src.ptr, src.ld,
-                     src.c, b, h, w, _ptr(packed), _ptr(gw), _stream())
+        with self._side(draw.buf, packed, gw):   # the weight gradient runs beside the data-gradient chain
+            self._launch(self._wgrad_label("conv3x3", cout, src.c), 2.0 * rows * cout * 9 * src.c, "ddpm_conv3x3_wgrad", draw.ptr, draw.ld, cout, src.ptr,
+                         src.ld, src.c, b, h, w, _ptr(packed), _ptr(gw), _stream())
         grads[conv + ".weight"] = gw
         dsrc = None
         if need_dsrc:
@@ -230,8 +251,9 @@ class TrainMixin:
                      dqp, _stream())
         grads[key + ".gamma"] = dgamma
         gw = torch.empty((lq, c), device=dev, dtype=torch.float32)
-        self._launch(self._wgrad_label("conv1x1", lq, c), 2.0 * b * n * lq * c, "ddpm_conv1x1_wgrad", dqkv.ptr, lq, lq, x.ptr, x.ld, c, b * n, _ptr(gw),
-                     _stream())
+        with self._side(dqkv.buf, gw):
+            self._launch(self._wgrad_label("conv1x1", lq, c), 2.0 * b * n * lq * c, "ddpm_conv1x1_wgrad", dqkv.ptr, lq, lq, x.ptr, x.ld, c, b * n,
+                         _ptr(gw), _stream())
         gb = torch.empty(lq, device=dev, dtype=torch.float32)
         call("ddpm_colsum", dqkv.ptr, lq, 1, b * n, lq, _ptr(ws), 0, _ptr(gb), _stream())
         for name, lo, cnt in (("query", 0, dq), ("key", dqp, dq), ("value", 2 * dqp, c)):
@@ -295,8 +317,9 @@ class TrainMixin:
             ukey = key + ".up"
             wt = self.T(ukey + ".weight")
             guw, packed = torch.empty_like(wt), torch.empty(wt.numel(), device=dev, dtype=torch.float32)
-            call("ddpm_convT2x2_wgrad", dup.ptr, dup.ld, cs, oh, ow, off_y, off_x, up_in.ptr, up_in.ld, up_in.c, b, h, w, _ptr(packed),
-                 _ptr(guw), _stream())
+            with self._side(dcat.buf, packed, guw):
+                call("ddpm_convT2x2_wgrad", dup.ptr, dup.ld, cs, oh, ow, off_y, off_x, up_in.ptr, up_in.ld, up_in.c, b, h, w, _ptr(packed),
+                     _ptr(guw), _stream())
             y0, x0 = max(off_y, 0), max(off_x, 0)
             y1, x1 = min(oh, off_y + 2 * h), min(ow, off_x + 2 * w)
             gub = torch.empty(cs, device=dev, dtype=torch.float32)
@@ -352,6 +375,8 @@ class TrainMixin:
                     field[k] = outs[nm].data_ptr()
         call("ddpm_time_embed_bwd", C.byref(g), _stream())
         grads.update(outs)
+        if self._s2 is not None:
+            torch.cuda.current_stream().wait_stream(self._s2)
         return grads
 
     def _pack_convT_dgrad(self, wt):
