@@ -256,9 +256,15 @@ def main():
     log("model built; settling")
     t_settle = time.perf_counter() + args.settle
     n_settle = 0
-    while time.perf_counter() < t_settle:
-        one_step()
-        n_settle += 1
+    if multi:
+        # every rank must issue the same number of collectives: a fixed count instead of a time budget
+        for _ in range(int(round(args.settle * 30))):
+            one_step()
+            n_settle += 1
+    else:
+        while time.perf_counter() < t_settle:
+            one_step()
+            n_settle += 1
     torch.cuda.synchronize()
     log(f"{n_settle} settling steps; warm-up")
     for _ in range(args.warmup):
