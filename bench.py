@@ -328,7 +328,7 @@ def main():
         "config": cfg,
         "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(kernel_peak(dom[0]), 1),
                      "unit": "TFLOP/s", "frac": round(achieved / kernel_peak(dom[0]), 4), "traffic": None,
-                     "sustained_peak": (SUSTAINED_BF16_TFLOPS / SPLIT_PRODUCTS if "split-bf16" in dom[0] else None),
+                     "sustained_peak": (round(SUSTAINED_BF16_TFLOPS / SPLIT_PRODUCTS, 1) if "split-bf16" in dom[0] else None),
                      "sustained_peak_note": "a loop of nothing but independent v_mfma_f32_32x32x16_bf16 (tools/probe/mfma_power.hip) "
                                             "sustains 1.9 PFLOP/s on this chip (1.8 GHz under that load, not the 2.4 GHz of the nominal peak)",
                      "arithmetic": ("fp32 operands split exactly into 3 bf16 terms, 6 cross products per fp32 product on "

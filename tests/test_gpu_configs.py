@@ -95,3 +95,33 @@ def test_eval_forward_is_independent_of_the_batch_cut(variant, hw):
         whole = run(slice(0, 24))
         parts = torch.cat([run(slice(0, 5)), run(slice(5, 16)), run(slice(16, 24))])
     assert torch.equal(whole, parts)
+
+
+def test_two_stream_backward_matches_one_stream():
+    """The weight gradients run on a second stream beside the data-gradient chain: same gradients as the
+    single-stream order (weight gradients are split-K atomic sums, so equal to rounding, not bit for bit),
+    step after step (the second step reuses memory the first one released)."""
+    from diffusion_model_amd.engine_train import TrainMixin
+    x = seeded_tensor((8, 1, 28, 28), 5, "x")
+    eps = seeded_tensor((8, 1, 28, 28), 6, "eps")
+    t = torch.tensor([3, 999, 500, 17, 0, 250, 731, 64])
+    results = []
+    saved = TrainMixin._use_side
+    try:
+        for side in (False, True):
+            TrainMixin._use_side = side
+            m = build(2, 1, 32, 64, 21)
+            m.train()
+            per_step = []
+            for _ in range(3):
+                m.zero_grad()
+                loss = torch.nn.functional.mse_loss(m(x.cuda(), t.cuda()), eps.cuda())
+                loss.backward()
+                torch.cuda.synchronize()
+                per_step.append({k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
+            results.append(per_step)
+    finally:
+        TrainMixin._use_side = saved
+    for a, b in zip(*results):
+        for k in a:
+            assert_close(b[k], a[k], 2e-5, f"two-stream gradient {k}")
