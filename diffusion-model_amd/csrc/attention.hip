@@ -36,6 +36,7 @@ struct AttnParams {
 
 template <int DQ, int NCT>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) {
+    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     constexpr int CS = 32 * NCT;      // value channels per workgroup
     constexpr int KLD = DQ + 4;       // padded K row (floats): 16-byte row reads stay conflict-free
     constexpr int VLD = CS;
@@ -49,9 +50,9 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z;
-    const int cbase = blockIdx.y * CS;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int b = bid.z;
+    const int cbase = bid.y * CS;
+    const int q0 = (bid.x * 4 + wave) * 32;
     const bool wave_active = q0 < p.n;          // wave-uniform
     const int qi = q0 + r;                      // this lane's query
     const float* base = p.qkv + static_cast<int64_t>(b) * p.n * p.lq;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
     const float inv_l = 1.0f / l_run;
     const float g = p.gamma[0];
     const int64_t pix = static_cast<int64_t>(b) * p.n + qi;
-    if (p.lse && h == 0 && blockIdx.y == 0) p.lse[pix] = m_run + logf(l_run);
+    if (p.lse && h == 0 && bid.y == 0) p.lse[pix] = m_run + logf(l_run);
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
 #pragma unroll
@@ -250,6 +251,7 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst, 
 
 template <int DQ>
 __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnParams p) {
+    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     constexpr int QB = 2;                       // 32-query blocks per wave
     constexpr int NCT = 2;                      // 32-channel blocks per workgroup
     constexpr int CS = 32 * NCT;
@@ -270,9 +272,9 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z;
-    const int cbase = blockIdx.y * CS;
-    const int q0 = (blockIdx.x * 4 + wave) * (32 * QB);
+    const int b = bid.z;
+    const int cbase = bid.y * CS;
+    const int q0 = (bid.x * 4 + wave) * (32 * QB);
     const bool wave_active = q0 < p.n;          // wave-uniform
     const float* base = p.qkv + static_cast<int64_t>(b) * p.n * p.lq;
 
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
         if (qi >= p.n) continue;
         const float inv_l = 1.0f / l_run[qb];
         const int64_t pix = static_cast<int64_t>(b) * p.n + qi;
-        if (p.lse && h == 0 && blockIdx.y == 0) p.lse[pix] = m_run[qb] + logf(l_run[qb]);
+        if (p.lse && h == 0 && bid.y == 0) p.lse[pix] = m_run[qb] + logf(l_run[qb]);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
 #pragma unroll

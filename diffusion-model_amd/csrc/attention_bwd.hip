@@ -75,6 +75,7 @@ __global__ void attn_bwd_dgamma_kernel(const double* __restrict__ partial, int n
 // slice 0 accumulates dK.
 template <int DQ, int NCT>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdParams p) {
+    const dim3 bid = blockIdx;   // launch order (measured: the XCD-grouped order is slower for this kernel's short key runs)
     constexpr int CS = 32 * NCT;
     constexpr int QLD = DQ + 4;
     constexpr int DT = (DQ + 31) / 32;
@@ -87,9 +88,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z;
-    const int cbase = blockIdx.y * CS;
-    const int j0 = (blockIdx.x * 4 + wave) * 32;
+    const int b = bid.z;
+    const int cbase = bid.y * CS;
+    const int j0 = (bid.x * 4 + wave) * 32;
     const bool wave_active = j0 < p.n;
     const int kj = j0 + r;  // this lane's key
     const float g = p.gamma[0];
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdParams p) {
             }
         }
         // dK^T[d][j] += sum_i Q[i][d] dS[i][j]
-        if (blockIdx.y == 0) {
+        if (bid.y == 0) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int d = dt * 32 + r;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdParams p) {
             f32x4 v = {dv[ct][gq * 4], dv[ct][gq * 4 + 1], dv[ct][gq * 4 + 2], dv[ct][gq * 4 + 3]};
             *reinterpret_cast<f32x4*>(drow + 2 * p.dqp + ch) = v;
         }
-    if (blockIdx.y == 0) {
+    if (bid.y == 0) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdParams p) {
 // ---- dQ: wave = 32 queries, loop over key tiles ------------------------------------------------
 template <int DQ>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdParams p) {
+    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     constexpr int KLD = DQ + 4;
     constexpr int DT = (DQ + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -242,8 +244,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z;
-    const int i0 = (blockIdx.x * 4 + wave) * 32;
+    const int b = bid.z;
+    const int i0 = (bid.x * 4 + wave) * 32;
     const bool wave_active = i0 < p.n;
     const int qi = i0 + r;
     const bool q_ok = qi < p.n;
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdParams p) {
 // the MFMAs of the current one, so one barrier per tile suffices and no load sits on the critical path.
 template <int DQ, int CT, int WPS>   // WPS = waves per SIMD the register budget is sized for
 __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_fast_kernel(const BwdParams p) {
+    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     constexpr int NCT = CT / 32;
     constexpr int QLD = DQ + 4, DLD = CT + 4;
     constexpr int DOPT = TQ * CT / 4 / 256;   // dO float4 per thread
@@ -368,8 +371,8 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_fast_kernel(const BwdPa
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z;
-    const int j0 = (blockIdx.x * 4 + wave) * 32;
+    const int b = bid.z;
+    const int j0 = (bid.x * 4 + wave) * 32;
     const bool wave_active = j0 < p.n;
     const int kj = j0 + r;
     const float g = p.gamma[0];
@@ -510,6 +513,7 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_fast_kernel(const BwdPa
 
 template <int DQ, int CT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_fast_kernel(const BwdParams p) {
+    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     constexpr int KLD = DQ + 4, VLD = CT + 4;
     constexpr int VPT = 32 * CT / 4 / 256;
     constexpr int KF4 = 32 * DQ / 4;
@@ -519,8 +523,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_fast_kernel(const BwdParam
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z;
-    const int i0 = (blockIdx.x * 4 + wave) * 32;
+    const int b = bid.z;
+    const int i0 = (bid.x * 4 + wave) * 32;
     const bool wave_active = i0 < p.n;
     const int qi = i0 + r;
     const bool q_ok = qi < p.n;
@@ -713,11 +717,12 @@ __device__ __forceinline__ int swz(int row, int ch) { return 256 * row + 16 * (c
 
 // Key-side gradients of 32 keys per wave. DK: dK (needs dP, hence V of all CT = C channels in
 // registers; the dO tile is only read row-wise and sits in padded rows). DV: dV for the CT channels
-// starting at blockIdx.y * CT (CT <= 128; the dO tile is read transposed and sits in swizzled 256-byte
+// starting at bid.y * CT (CT <= 128; the dO tile is read transposed and sits in swizzled 256-byte
 // rows). Both at once when the registers allow (C <= 128); wider layers run the two halves as separate
 // launches, each recomputing the scores (depth-DQ products, cheap beside the C-deep ones).
 template <int DQ, int CT, bool DK, bool DV, int WPS = 1>
 __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdParams p) {
+    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     static_assert(!DV || CT <= 128, "transposed dO reads assume 256-byte rows");
     constexpr int NCT = CT / 32, KCV = CT / 16;
     constexpr int KD = DQ < 16 ? 16 : DQ, KQ = KD / 16;   // padded depth, 16-deep chunks of it
@@ -734,9 +739,9 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z;
-    const int c0 = blockIdx.y * CT;
-    const int j0 = (blockIdx.x * 4 + wave) * 32;
+    const int b = bid.z;
+    const int c0 = bid.y * CT;
+    const int j0 = (bid.x * 4 + wave) * 32;
     const bool wave_active = j0 < p.n;
     const int kj = j0 + r;
     const bool k_ok = kj < p.n;
@@ -944,6 +949,7 @@ constexpr int dkv_x3_lds() {
 // Query-side gradient of 32 queries per wave (dO of all CT = C channels in registers).
 template <int DQ, int CT>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams p) {
+    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     constexpr int KCV = CT / 16;
     constexpr int KD = DQ < 16 ? 16 : DQ, KQ = KD / 16;
     constexpr int KROW = 2 * KD, KPLANE = 32 * KROW;
@@ -958,8 +964,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z;
-    const int i0 = (blockIdx.x * 4 + wave) * 32;
+    const int b = bid.z;
+    const int i0 = (bid.x * 4 + wave) * 32;
     const bool wave_active = i0 < p.n;
     const int qi = i0 + r;
     const bool q_ok = qi < p.n;

@@ -44,6 +44,21 @@ inline bool split_math() {
     return on;
 }
 
+#ifdef __HIPCC__
+// Workgroups are dispatched in linear order (x fastest) and handed to the 8 XCDs round-robin, and every
+// XCD has its own L2. This returns the block index a kernel should WORK on so that consecutive linear
+// indices (the workgroups that share a sample's operands) run on ONE XCD and find each other's data in
+// its L2, instead of each fetching its own copy over the fabric.
+__device__ __forceinline__ dim3 xcd_block() {
+    const unsigned nx = gridDim.x, ny = gridDim.y;
+    const unsigned total = nx * ny * gridDim.z;
+    const unsigned id = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const unsigned q = total >> 3, rr = total & 7, xcd = id & 7;
+    const unsigned nid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+    return dim3(nid % nx, (nid / nx) % ny, nid / (nx * ny));
+}
+#endif
+
 }  // namespace ddpm
 
 #define DDPM_REQUIRE(cond)                          \

@@ -98,10 +98,20 @@ class UNetEngine(TrainMixin):
         self._prof_i += 1
         if self._prof_i % self.prof_stride:
             return call(name, *args)
+        # a bracketed launch runs alone: the other stream of the training backward is drained first and held
+        # until the kernel is done, so that the events time this kernel and not its share of a busy chip
+        cur, other = torch.cuda.current_stream(), None
+        s2 = getattr(self, "_s2", None)
+        if s2 is not None:
+            other = self._main_stream if cur == s2 else s2
+            if other is not None:
+                cur.wait_stream(other)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         call(name, *args)
         e1.record()
+        if other is not None:
+            other.wait_event(e1)
         self.prof.append((label, flops, e0, e1))
 
     # ------------------------------------------------------------------ entry point

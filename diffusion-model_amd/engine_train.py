@@ -28,6 +28,7 @@ def _stream():
 
 class TrainMixin:
     _s2 = None                                                      # second stream of the backward pass (weight gradients)
+    _main_stream = None                                             # the stream the backward itself runs on (set when _s2 is used)
     _use_side = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # diagnostic switch: "0" keeps the backward on one stream
 
     # ------------------------------------------------------------------ scratch
@@ -183,6 +184,7 @@ class TrainMixin:
         main = torch.cuda.current_stream()
         if self._s2 is None:
             self._s2 = torch.cuda.Stream(device=main.device)
+        self._main_stream = main
         self._s2.wait_stream(main)
         for t in tensors:
             t.record_stream(self._s2)
