@@ -321,13 +321,26 @@ def main():
                    parallelism=("dp%d: %s all-reduce of flattened gradients" % (world, "RCCL" if args.backend == "nccl" else args.backend))
                    if multi else "single GPU",
                    last_loss=round(state["loss"], 5))
+    # memory-side bytes per launch of the dominant kernel: not measurable live (hardware counters need their own
+    # rocprofv3 --pmc passes), so taken from the committed summary of tools/pmc_traffic.sh for this workload
+    traffic, traffic_src = None, None
+    kernel_symbol = {"conv3x3_halo<split-bf16>": "conv3x3_halo_kernel", "attention_fwd<split-bf16>": "attention_fwd_x3_kernel"}.get(dom[0])
+    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.txt" % ("sample" if args.workload == "sample" else "train"))
+    if kernel_symbol and args.workload in ("train", "sample") and os.path.exists(tfile):
+        for line in open(tfile):
+            f = line.split()
+            if len(f) > 4 and kernel_symbol in line and f[0].isdigit():
+                traffic = int(float(f[3]) * 1e6)
+                traffic_src = ("bytes per launch, mean over this kernel's launches of one step: rocprofv3 --pmc FETCH_SIZE (x 2, the gfx950 "
+                               "correction for wide loads) + WRITE_SIZE in separate passes, profiles/" + os.path.basename(tfile))
+                break
     out = {
         "metric": wl["metric"], "value": round(value, 4), "unit": wl["unit"],
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": cfg,
         "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(kernel_peak(dom[0]), 1),
-                     "unit": "TFLOP/s", "frac": round(achieved / kernel_peak(dom[0]), 4), "traffic": None,
+                     "unit": "TFLOP/s", "frac": round(achieved / kernel_peak(dom[0]), 4), "traffic": traffic, "traffic_source": traffic_src,
                      "sustained_peak": (round(SUSTAINED_BF16_TFLOPS / SPLIT_PRODUCTS, 1) if "split-bf16" in dom[0] else None),
                      "sustained_peak_note": "a loop of nothing but independent v_mfma_f32_32x32x16_bf16 (tools/probe/mfma_power.hip) "
                                             "sustains 1.9 PFLOP/s on this chip (1.8 GHz under that load, not the 2.4 GHz of the nominal peak)",
