@@ -12,6 +12,7 @@
 //                   exactly the key that register holds in each lane half), so the probabilities
 //                   never leave the register file. The output tile again has lane = query, so the
 //                   online-softmax rescale is a per-lane multiply.
+#include "attention_small.h"
 #include "common.h"
 
 namespace {
@@ -548,6 +549,8 @@ extern "C" int ddpm_attention_fwd(const float* qkv, const float* x, int ldx, con
     p.ldx = ldx;
     p.ldo = ldo;
     hipStream_t s = ddpm::as_stream(stream);
+    if (ddpm::small_attention() && ddpm::attention_small_fwd_fits(n, c, dq))
+        return ddpm::attention_small_fwd(qkv, x, ldx, gamma, temb, out, ldo, attn_raw, lse, batch, n, c, dq, s);
     switch (dq) {
         case 8: return launch_dq<8>(p, batch, s);
         case 16: return launch_dq<16>(p, batch, s);

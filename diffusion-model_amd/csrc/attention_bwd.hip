@@ -11,6 +11,7 @@
 // "lane = key, register = query" orientation, so the query-axis contractions for dV and dK take the
 // score registers directly as MFMA B operands); `dq` gives every wave 32 queries and walks the keys
 // in the transposed orientation. The x-gradient pass-through (dx += dY) is the caller's.
+#include "attention_small.h"
 #include "common.h"
 
 namespace {
@@ -1196,6 +1197,8 @@ extern "C" int ddpm_attention_bwd(const float* qkv, const float* dy, int ldd, co
     attn_bwd_pre_kernel<<<pre_blocks, 256, 0, s>>>(dy, ldd, attn_raw, c, rows, e_scratch, workspace);
     attn_bwd_dgamma_kernel<<<1, 256, 0, s>>>(workspace, pre_blocks, dgamma);
     if (int rc = ddpm::check_launch("attn_bwd_pre")) return rc;
+    if (ddpm::small_attention() && ddpm::attention_small_bwd_fits(n, c, dq))
+        return ddpm::attention_small_bwd(qkv, dy, ldd, lse, e_scratch, gamma, dqkv, batch, n, c, dq, s);
     BwdParams p;
     p.qkv = qkv;
     p.dy = dy;

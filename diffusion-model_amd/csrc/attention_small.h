@@ -1,0 +1,18 @@
+// One-workgroup-per-sample attention for feature maps of at most 64 pixels (attention_small.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ddpm {
+
+bool attention_small_fwd_fits(int n, int c, int dq);
+bool attention_small_bwd_fits(int n, int c, int dq);
+
+// operands as in ddpm_attention_fwd; dq is the padded q/k width
+int attention_small_fwd(const float* qkv, const float* x, int ldx, const float* gamma, const float* temb, float* out, int ldo,
+                        float* attn_raw, float* lse, int batch, int n, int c, int dq, hipStream_t s);
+
+// operands as in ddpm_attention_bwd after its row-sum pass: e[b][i] = dY[i] . O[i]
+int attention_small_bwd(const float* qkv, const float* dy, int ldd, const float* lse, const float* e, const float* gamma, float* dqkv,
+                        int batch, int n, int c, int dq, hipStream_t s);
+
+}  // namespace ddpm

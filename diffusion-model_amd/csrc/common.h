@@ -44,6 +44,16 @@ inline bool split_math() {
     return on;
 }
 
+// DDPM_ATTN_SMALL=0 (read once) routes feature maps of at most 64 pixels through the tiled attention
+// kernels instead of the one-workgroup-per-sample ones: a diagnostic switch for A/B measurements.
+inline bool small_attention() {
+    static const bool on = [] {
+        const char* e = getenv("DDPM_ATTN_SMALL");
+        return !(e && strcmp(e, "0") == 0);
+    }();
+    return on;
+}
+
 #ifdef __HIPCC__
 // Workgroups are dispatched in linear order (x fastest) and handed to the 8 XCDs round-robin, and every
 // XCD has its own L2. This returns the block index a kernel should WORK on so that consecutive linear
