@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--workload", default="train", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--optimizer", default="hip", choices=["hip", "torch"], help="training: diffusion_model_amd.optim.Adam or torch.optim.Adam")
     ap.add_argument("--profile-stride", type=int, default=7,
                     help="bracket every N-th MFMA launch of the timed steps with HIP events (1 = all; events cost GPU time)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
@@ -182,7 +183,8 @@ def main():
             state["x"], state["t"] = out, t - 1
     else:
         model.train()
-        opt = torch.optim.Adam(model.parameters(), lr=2e-4)
+        from diffusion_model_amd.optim import Adam
+        opt = (torch.optim.Adam if args.optimizer == "torch" else Adam)(model.parameters(), lr=2e-4)
         crit = torch.nn.MSELoss()
         data = (torch.rand(shape, generator=gen) * 2 - 1).to(dev)            # synthetic MNIST-shaped batch in [-1, 1]
         params = [p for p in model.parameters()]
@@ -317,7 +319,7 @@ def main():
         cfg.update(T=T_FULL, step="one denoising step (UNet eval forward + noise draw + fused reverse-step kernel); "
                                   "images/s = global_batch / (T * seconds_per_step)")
     else:
-        cfg.update(optimizer="torch.optim.Adam(lr=2e-4)", batchnorm="per-rank batch statistics",
+        cfg.update(optimizer=("torch.optim.Adam(lr=2e-4)" if args.optimizer == "torch" else "Adam(lr=2e-4), torch.optim.Adam's update as one HIP launch per 64 tensors"), batchnorm="per-rank batch statistics",
                    parallelism=("dp%d: %s all-reduce of flattened gradients" % (world, "RCCL" if args.backend == "nccl" else args.backend))
                    if multi else "single GPU",
                    last_loss=round(state["loss"], 5))

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "ddpm_time_embed_bwd": [C.POINTER(EmbedBwdArgs), P],
     "ddpm_attention_bwd": [P, P, I32, P, P, P, P, P, P, P, I32, I32, I32, I32, P],
     "ddpm_attention_fwd": [P, P, I32, P, P, I32, P, P, P, I32, I32, I32, I32, P],
+    "ddpm_adam_step": [I32, P, P, P, P, P, F64, F64, F64, F64, F64, I64, P],
 }
 
 _lib = None

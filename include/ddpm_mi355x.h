@@ -90,6 +90,16 @@ int ddpm_mse_fwd(const float* pred, const float* target, int64_t n, double* part
 int ddpm_mse_bwd(const float* pred, const float* target, const float* gout, int64_t n, float* grad,
                  void* stream);
 
+/* Adam update of ntensors tensors (host arrays of device pointers and element counts; the arrays are
+ * consumed before the call returns): exp_avg = lerp(exp_avg, grad, 1-beta1); exp_avg_sq = beta2*exp_avg_sq
+ * + (1-beta2)*grad^2; param -= lr/(1-beta1^step) * exp_avg / (sqrt(exp_avg_sq)/sqrt(1-beta2^step) + eps);
+ * weight_decay > 0 adds weight_decay*param to grad first (L2, as torch.optim.Adam). step >= 1 is the
+ * count AFTER this update. Replaces optimizer.step() of optim.Adam(model.parameters(), lr),
+ * first-iteration/main.py:51,84; third-iteration/main.py:61. */
+int ddpm_adam_step(int ntensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const int64_t* numel, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, int64_t step, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Time / label embedding: sinusoidal embedding followed by the four time Linears (and, when
  * labels are given, the label Embedding + four label Linears added on top).

@@ -20,6 +20,7 @@ from conftest import GOLDEN, load_golden
 from gpu_util import assert_close
 from seeding import seeded_ints, seeded_state_dict, seeded_tensor
 import diffusion_model_amd as pkg
+from diffusion_model_amd.optim import Adam
 
 pytestmark = pytest.mark.gpu
 
@@ -76,12 +77,13 @@ def test_parameter_gradients(variant, hw):
     assert worst[0][0] <= 1.0, worst[:8]
 
 
-def test_ten_adam_steps_match_reference_losses():
+@pytest.mark.parametrize("optimizer", ["torch", "hip"])
+def test_ten_adam_steps_match_reference_losses(optimizer):
     g = load_golden("training_v2.npz")
     m = build(2, 2).train()
     betas = pkg.BetaScheduler(1000, device="cuda").get_schedule("linear")
     dm = pkg.make_diffusion_class(2)(m, betas, 1000)
-    opt = torch.optim.Adam(m.parameters(), lr=2e-4)
+    opt = (torch.optim.Adam if optimizer == "torch" else Adam)(m.parameters(), lr=2e-4)
     crit = torch.nn.MSELoss()
     losses = []
     for s in range(10):
@@ -111,3 +113,90 @@ def test_grad_needs_train_mode_and_no_input_grad():
     m.train()
     with pytest.raises(NotImplementedError):
         m(x.requires_grad_(True), t)
+
+
+def _adam_tensors(seed, n_tensors=70):
+    """More tensors than one launch holds; odd sizes, one empty, one view that is not 16-byte aligned."""
+    gen = torch.Generator().manual_seed(seed)
+    sizes = [(0,), (1,), (3,), (5, 7), (64,), (1023,), (4, 3, 3, 8), (257, 129), (300001,)] + [(i + 2, 5) for i in range(n_tensors - 9)]
+    out = []
+    for i, sz in enumerate(sizes):
+        t = torch.randn(*sz, generator=gen)
+        out.append(t)
+    return out
+
+
+@pytest.mark.parametrize("weight_decay", [0.0, 0.01])
+def test_adam_matches_torch_and_oracle(weight_decay):
+    """Six steps of the HIP Adam against torch.optim.Adam on the GPU and the CPU oracle's restatement.
+    fp32 tolerance: the update is a handful of roundings per element (the two sides may contract
+    multiply-adds differently), so 2e-6 relative on parameters and moments."""
+    import oracle.ddpm_oracle as O
+    init = _adam_tensors(1)
+    base = torch.randn(3 + init[-1].numel()).cuda()
+    ours = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    ours[-1] = torch.nn.Parameter(base[3:].view_as(init[-1]).copy_(init[-1].cuda()))   # 12 bytes off a 16-byte boundary
+    assert ours[-1].data_ptr() % 16 == 12
+    theirs = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    a = Adam(ours, lr=2e-3, weight_decay=weight_decay)
+    b = torch.optim.Adam(theirs, lr=2e-3, weight_decay=weight_decay, foreach=False)
+    oparams = {str(i): t.clone() for i, t in enumerate(init)}
+    ostate = {}
+    for step in range(6):
+        grads = [g * (0.5 + step) for g in _adam_tensors(100 + step)]
+        for p, q, g in zip(ours, theirs, grads):
+            p.grad = g.cuda()
+            q.grad = g.cuda()
+        if step == 3:
+            ours[5].grad = None            # a parameter without a gradient keeps its value and its step count
+            theirs[5].grad = None
+        a.step()
+        b.step()
+        if weight_decay == 0.0 and step < 3:
+            O.adam_step(oparams, {str(i): g for i, g in enumerate(grads)}, ostate, lr=2e-3)
+            for i, p in enumerate(ours):
+                torch.testing.assert_close(p.detach().cpu(), oparams[str(i)], rtol=2e-6, atol=1e-7)
+    for i, (p, q) in enumerate(zip(ours, theirs)):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-6, atol=1e-7, msg=lambda m: f"tensor {i}: {m}")
+        if p.numel():
+            torch.testing.assert_close(a.state[p]["exp_avg"], b.state[q]["exp_avg"], rtol=2e-6, atol=1e-9)
+            torch.testing.assert_close(a.state[p]["exp_avg_sq"], b.state[q]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+            assert float(a.state[p]["step"]) == float(b.state[q]["step"])
+
+
+def test_adam_state_dict_moves_both_ways():
+    """The optimizer state has torch.optim.Adam's layout: a checkpoint of either loads into the other."""
+    init = _adam_tensors(2, 12)
+    grads = [[g.cuda() for g in _adam_tensors(50 + s, 12)] for s in range(4)]
+    ours = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    theirs = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    a, b = Adam(ours, lr=1e-3), torch.optim.Adam(theirs, lr=1e-3)
+    for s in range(2):
+        for p, q, g in zip(ours, theirs, grads[s]):
+            p.grad, q.grad = g, g.clone()
+        a.step()
+        b.step()
+    # swap the states, then continue: each side must land where the other would have
+    sa, sb = a.state_dict(), b.state_dict()
+    a2, b2 = Adam(ours, lr=1e-3), torch.optim.Adam(theirs, lr=1e-3)
+    a2.load_state_dict(sb)
+    b2.load_state_dict(sa)
+    for s in range(2, 4):
+        for p, q, g in zip(ours, theirs, grads[s]):
+            p.grad, q.grad = g, g.clone()
+        a2.step()
+        b2.step()
+    for p, q in zip(ours, theirs):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-6, atol=1e-7)
+
+
+def test_adam_rejects_what_it_does_not_implement():
+    p = [torch.nn.Parameter(torch.zeros(4, device="cuda"))]
+    with pytest.raises(NotImplementedError):
+        Adam(p, amsgrad=True)
+    with pytest.raises(ValueError):
+        Adam(p, lr=-1.0)
+    cpu = torch.nn.Parameter(torch.zeros(4))
+    cpu.grad = torch.zeros(4)
+    with pytest.raises(RuntimeError):
+        Adam([cpu]).step()
