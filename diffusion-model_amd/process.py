@@ -102,7 +102,13 @@ class _DiffusionBase:
             if x_t.shape != x_shape:
                 raise ValueError(f"Unexpected shape after update: {x_t.shape}, expected: {x_shape}")
             if t % (T // 10) == 0 or t == 0:
-                stages.append((x_t.clone().detach().cpu(), t))
+                # stage hand-off (the reference's x_t.clone().detach().cpu()): an asynchronous copy into pinned
+                # memory, ordered on the stream behind the step that produced x_t; one wait at the end instead
+                # of one per stage
+                host = torch.empty(x_t.shape, dtype=x_t.dtype, pin_memory=True)
+                host.copy_(x_t, non_blocking=True)
+                stages.append((host, t))
+        torch.cuda.current_stream(x_t.device).synchronize()
         return stages
 
 
