@@ -32,6 +32,7 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
 FP32_MFMA_PEAK_TFLOPS = 157.3     # gfx950 dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 BF16_MFMA_PEAK_TFLOPS = 2516.6    # gfx950 dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
 SPLIT_PRODUCTS = 6                # bf16 MFMA products per fp32 product in the split-bf16 kernels
+HBM_PEAK_GBPS = 8000.0            # HBM3E peak of one MI355X
 SUSTAINED_BF16_TFLOPS = 1900.0    # measured: pure-MFMA loop, two waves per SIMD (tools/probe/mfma_power.hip)
 
 
@@ -68,6 +69,33 @@ def build_model(variant, cin, labels):
     m = U(cin, cin, 64, 128, num_classes=10) if (variant == 3 and labels) else U(cin, cin, 64, 128)
     m.load_state_dict(seeded_state_dict(m.state_dict(), 0))      # non-trivial BN statistics and attention gates
     return m
+
+
+def reverse_step_bandwidth(dev, loop_elements, big=1 << 26, iters=20):
+    """The fused reverse-step kernel (x_{t-1} from x_t, eps-hat, z: 16 algorithmic bytes per element) against the HBM
+    peak, timed with HIP events outside the timed steps: at 2^26 elements, where every operand comes from HBM, and at
+    the size one denoising step of this workload launches it with (small enough to stay in the caches)."""
+    import ctypes as C
+    from diffusion_model_amd._lib import call
+    res = {"kernel": "reverse_step", "bytes_per_element": 16, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+    for tag, n in (("hbm_resident", big), ("loop_size", loop_elements)):
+        x, eps, z, out = (torch.randn(n, device=dev) for _ in range(4))
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        fn = lambda: call("ddpm_reverse_step", C.c_void_p(x.data_ptr()), C.c_void_p(eps.data_ptr()), None, 0.0,  # noqa: E731
+                          C.c_void_p(z.data_ptr()), 1.01, 0.02, 0.1, C.c_void_p(out.data_ptr()), n, st)
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        gbps = 16.0 * n / (ms * 1e-3) / 1e9
+        res[tag] = {"elements": n, "avg_ms": round(ms, 4), "achieved": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+        del x, eps, z, out
+    return res
 
 
 def cpu_baseline(workload, wl, seconds=12.0):
@@ -355,6 +383,8 @@ def main():
         "kernels": kernels,
     }
     if rank == 0:
+        if not multi:
+            out["hbm_kernel"] = reverse_step_bandwidth(dev, B * wl["cin"] * wl["hw"] * wl["hw"])
         if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, wl)
         print(json.dumps(out), flush=True)
