@@ -1,3 +1,5 @@
+"""Manual checker (not collected by pytest): per-parameter gradient error of one full-width train step against the
+CPU oracle.   python tests/debug_grad.py [batch] [hw]"""
 import sys, os, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
