@@ -274,14 +274,29 @@ __global__ __launch_bounds__(kThreads) void embed_bwd_weight_kernel(const EmbedB
     const int co = i / E, e = i % E;
     const float* g = a.dtemb[k];
     double s = 0.0, sl = 0.0, sb = 0.0;
-    for (int b = 0; b < a.batch; ++b) {
-        const float gv = g[static_cast<int64_t>(b) * C + co];
-        s += static_cast<double>(gv) * a.emb[static_cast<int64_t>(b) * E + e];
-        if (a.n_labels > 0) {
-            const int64_t cls = a.y[a.n_labels == 1 ? 0 : b];
-            sl += static_cast<double>(gv) * a.label_table[cls * E + e];
+    // eight samples' operands are requested before any is used (the loop is bound by load latency);
+    // the sums still run over the batch in order
+    constexpr int U = 8;
+    for (int b0 = 0; b0 < a.batch; b0 += U) {
+        float gv[U], ev[U], lv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u < a.batch ? b0 + u : a.batch - 1;
+            gv[u] = g[static_cast<int64_t>(b) * C + co];
+            ev[u] = a.emb[static_cast<int64_t>(b) * E + e];
+            lv[u] = 0.f;
+            if (a.n_labels > 0) {
+                const int64_t cls = a.y[a.n_labels == 1 ? 0 : b];
+                lv[u] = a.label_table[cls * E + e];
+            }
         }
-        sb += gv;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (b0 + u >= a.batch) break;
+            s += static_cast<double>(gv[u]) * ev[u];
+            if (a.n_labels > 0) sl += static_cast<double>(gv[u]) * lv[u];
+            sb += gv[u];
+        }
     }
     a.dw[k][i] = static_cast<float>(s);
     if (e == 0) a.db[k][co] = static_cast<float>(sb);
