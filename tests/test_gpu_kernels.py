@@ -294,3 +294,25 @@ def test_attention_large_logits_rescale():
     keep = [qkv.cuda(), x.cuda(), torch.ones(1, device="cuda")]
     call("ddpm_attention_fwd", P(keep[0]), P(keep[1]), c, P(keep[2]), P(out), c, None, None, None, B, N, c, dq, stream())
     assert_close(out.cpu(), want, TOL, "attention rescale")
+
+
+def test_adam_step_argument_checks():
+    """ddpm_adam_step through the raw C ABI: an empty list is a no-op, bad arguments return an error code."""
+    from diffusion_model_amd import _lib
+    h = _lib.lib()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert h.ddpm_adam_step(0, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, s) == 0
+    init = [1.0, 1.0, 0.0, 0.0]                                                          # param, grad, exp_avg, exp_avg_sq
+    t = [torch.full((5,), v, device="cuda") for v in init]
+    arrs = [(C.c_void_p * 1)(x.data_ptr()) for x in t]
+    n = (C.c_int64 * 1)(5)
+    assert h.ddpm_adam_step(1, *arrs, n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, s) != 0          # step counts from 1
+    assert h.ddpm_adam_step(1, *arrs, n, 1e-3, 1.0, 0.999, 1e-8, 0.0, 1, s) != 0          # beta1 < 1
+    assert h.ddpm_adam_step(1, arrs[0], None, arrs[2], arrs[3], n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, s) != 0
+    assert b"invalid argument" in h.ddpm_last_error()
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, torch.full((5,), v, device="cuda")) for x, v in zip(t, init))   # nothing was touched
+    assert h.ddpm_adam_step(1, *arrs, n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, s) == 0
+    torch.cuda.synchronize()
+    # first step of Adam from m = v = 0 with g = 1: the update is lr * 1 / (1 + eps)
+    torch.testing.assert_close(t[0], torch.full((5,), 1.0 - 1e-3, device="cuda"), rtol=1e-6, atol=0)

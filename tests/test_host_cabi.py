@@ -91,3 +91,26 @@ def test_drop_in_modules_import_by_bare_name():
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert r.stdout.split() == ["UNet", "DiffusionModel", "BetaScheduler", "SinusoidalTimeEmbedding"]
+
+
+def test_adam_host_side_contract():
+    """Constructor checks and state layout of the HIP Adam mirror torch.optim.Adam (no GPU call involved)."""
+    from diffusion_model_amd.optim import Adam
+    p = [torch.nn.Parameter(torch.zeros(4))]
+    for bad in (dict(lr=-1.0), dict(eps=-1.0), dict(betas=(1.0, 0.999)), dict(betas=(0.9, -0.1)), dict(weight_decay=-1.0)):
+        with pytest.raises(ValueError):
+            Adam(p, **bad)
+        with pytest.raises(ValueError):
+            torch.optim.Adam(p, **bad)
+    with pytest.raises(NotImplementedError):
+        Adam(p, amsgrad=True)
+    with pytest.raises(NotImplementedError):
+        Adam(p, maximize=True)
+    ours, theirs = Adam(p, lr=2e-4), torch.optim.Adam(p, lr=2e-4)
+    for k in ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize"):
+        assert ours.param_groups[0][k] == theirs.param_groups[0][k], k
+    ours.step()                              # no gradient anywhere: nothing to launch, nothing raised
+    assert ours.state_dict()["state"] == {}
+    p[0].grad = torch.zeros(4)
+    with pytest.raises(RuntimeError):        # CPU parameters have no path
+        ours.step()
