@@ -333,6 +333,14 @@ def main():
         a[0] += flops
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
+    if os.environ.get("DDPM_BENCH_PER_SHAPE") and rank == 0:   # diagnostic: the same figures per distinct launch shape
+        shapes = {}
+        for label, flops, e0, e1 in prof:
+            a = shapes.setdefault((label, flops), [0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += 1
+        for (label, flops), (t, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
+            log(f"  {label:40s} {flops / 1e9:9.2f} GFLOP  x{n:3d}  {t / n * 1e6:8.1f} us  {flops * n / t / 1e12:6.1f} TFLOP/s")
     if not agg:
         sys.exit(f"no MFMA launch was sampled: lower --profile-stride ({sec_per_step * 1e3:.3f} ms/step)")
     dom = max(agg.items(), key=lambda kv: kv[1][1])
