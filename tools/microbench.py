@@ -54,7 +54,7 @@ def main():
         y = torch.empty(B, H, W, co, device=dev)
         flops = 2.0 * B * H * W * co * ci * 9
         if kind == "conv3x3":
-            d = ConvDesc(batch=B, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=2, ldr=0, out_h=H, out_w=W)
+            d = ConvDesc(batch=B, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=int(os.environ.get("MB_ACT", "2")), ldr=0, out_h=H, out_w=W)
             sc, sh = torch.ones(co, device=dev), torch.zeros(co, device=dev)
             ep = Epilogue(P(sc), P(sh), None, None)
             t = timeit(lambda: call("ddpm_conv3x3_fwd", C.byref(d), P(x), None, P(wp), C.byref(ep), P(y), S()), iters)
