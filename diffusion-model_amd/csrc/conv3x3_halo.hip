@@ -275,32 +275,42 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
         else if (my_slots == 1) k_loop(T1{});
         else k_loop(T0{});
 
-        // ---- epilogue (32-bit offsets from the tile's first pixel) ----------------------------
+        // ---- epilogue -----------------------------------------------------------------------
+        // Stores and residual loads go through buffer descriptors that begin at the tile's first pixel
+        // and end with the tensor: rows past the last pixel fall outside and are dropped (or read as
+        // zero) by the hardware's range check, so no element carries a compare, a select or a branch.
         int n = n0 + wn * 32 + r;
         int hq = 4 * h;
         asm volatile("" : "+v"(n), "+v"(hq));   // keeps the 64 per-element offsets below from being hoisted out of the tile loop
         if (n < p.n_total && (!(DDPM_HALO_ABLATE & 16) || p.act == 77)) {
             const float sc = p.scale ? p.scale[n] : 1.0f;
             const float sh = p.shift ? p.shift[n] : 0.0f;
-            float* out_t = p.out + static_cast<int64_t>(m0) * p.ldo;
-            const float* res_t = p.residual ? p.residual + static_cast<int64_t>(m0) * p.ldr : nullptr;
+            const long long rows_left = p.m_total - m0;
+            const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out + static_cast<int64_t>(m0) * p.ldo, rows_left * p.ldo * 4ll);
+            const __amdgpu_buffer_rsrc_t rs_r =
+                make_rsrc(p.residual ? p.residual + static_cast<int64_t>(m0) * p.ldr : p.out, p.residual ? rows_left * p.ldr * 4ll : 0ll);
+            const unsigned vo = static_cast<unsigned>((wm * 32 + hq) * p.ldo + n) * 4u;
+            const unsigned vr = static_cast<unsigned>((wm * 32 + hq) * p.ldr + n) * 4u;
+            const unsigned ldo4 = static_cast<unsigned>(p.ldo) * 4u, ldr4 = static_cast<unsigned>(p.ldr) * 4u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i >= my_slots) continue;
 #pragma unroll
                 for (int eq = 0; eq < 4; ++eq) {
-                    const int row0 = (i * WM + wm) * 32 + 8 * eq + hq;   // rows row0 .. row0 + 3
-                    const int4 bs = *reinterpret_cast<const int4*>(&rowb[row0]);
-                    const int bb[4] = {bs.x, bs.y, bs.z, bs.w};
+                    const int rel0 = i * WM * 32 + 8 * eq;            // rows rel0 + (wm * 32 + hq) + 0 .. 3
+                    int bb[4] = {0, 0, 0, 0};
+                    if (p.temb) {
+                        const int4 bs = *reinterpret_cast<const int4*>(&rowb[rel0 + wm * 32 + hq]);
+                        bb[0] = bs.x; bb[1] = bs.y; bb[2] = bs.z; bb[3] = bs.w;
+                    }
 #pragma unroll
                     for (int ei = 0; ei < 4; ++ei) {
-                        const int row = row0 + ei;
-                        const int b = bb[ei];
+                        const unsigned rel = static_cast<unsigned>(rel0 + ei);
                         float v = master[i][eq * 4 + ei] * sc + sh;
-                        if (res_t) v += b >= 0 ? res_t[static_cast<unsigned>(row * p.ldr + n)] : 0.f;
+                        if (p.residual) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, vr + rel * ldr4, 0, 0));
                         v = apply_act_fast(v, p.act);
-                        if (p.temb) v += b >= 0 ? p.temb[static_cast<unsigned>(b * p.cout + n)] : 0.f;
-                        if (b >= 0) out_t[static_cast<unsigned>(row * p.ldo + n)] = v;
+                        if (p.temb) v += bb[ei] >= 0 ? p.temb[static_cast<unsigned>(bb[ei] * p.cout + n)] : 0.f;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, vo + rel * ldo4, 0, 0);
                     }
                 }
             }

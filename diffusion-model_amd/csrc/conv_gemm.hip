@@ -540,6 +540,45 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
         else k_loop(T0{});
 
         // ---- epilogue ---------------------------------------------------------------------
+        // Rows that are consecutive pixels of the tensor (every 1x1 conv, a 3x3 conv over the whole
+        // image): stores and residual loads go through buffer descriptors that begin at the tile's first
+        // pixel and end with the tensor, so rows past the last pixel are dropped (or read as zero) by the
+        // range check and no element carries a row lookup, a branch or 64-bit address arithmetic.
+        const bool linear_rows = MODE != MODE_CONVT && p.win_y0 == 0 && p.win_x0 == 0 && p.win_h == p.in_h && p.win_w == p.in_w;
+        if (linear_rows) {
+            const long long rows_left = p.m_total - m0;
+            const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out + static_cast<int64_t>(m0) * p.ldo, rows_left * p.ldo * 4ll);
+            const __amdgpu_buffer_rsrc_t rs_r =
+                make_rsrc(p.residual ? p.residual + static_cast<int64_t>(m0) * p.ldr : p.out, p.residual ? rows_left * p.ldr * 4ll : 0ll);
+            const unsigned ldo4 = static_cast<unsigned>(p.ldo) * 4u, ldr4 = static_cast<unsigned>(p.ldr) * 4u;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int n = n0 + (wn * TN + j) * 32 + r;
+                asm volatile("" : "+v"(n));   // keeps the per-element offsets from being hoisted out of the tile loop
+                if (n >= p.n_total) continue;
+                const float sc = p.scale ? p.scale[n] : 1.0f;
+                const float sh = p.shift ? p.shift[n] : 0.0f;
+                const unsigned vo = static_cast<unsigned>((wm * 32 + 4 * h) * p.ldo + n) * 4u;
+                const unsigned vr = static_cast<unsigned>((wm * 32 + 4 * h) * p.ldr + n) * 4u;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i >= my_slots) continue;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const unsigned rel = static_cast<unsigned>(i * 64 + (e & 3) + 8 * (e >> 2));   // + wm * 32 + 4 * h
+                        float v = master[i][j][e] * sc + sh;
+                        if (p.residual) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, vr + rel * ldr4, 0, 0));
+                        v = apply_act_fast(v, p.act);
+                        if (p.temb) {
+                            const int4 info = rowinfo[rel + wm * 32 + 4 * h];
+                            v += info.x >= 0 ? p.temb[static_cast<int64_t>(info.y) * p.cout + n] : 0.f;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, vo + rel * ldo4, 0, 0);
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + (wn * TN + j) * 32 + r;
