@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void vec_final_kernel(const double* __res
 
 // ---- time / label embedding Linears backward -------------------------------------------------
 struct EmbedBwd {
-    int batch, emb_dim, n_labels;
+    int batch, emb_dim, n_labels, n_classes;
     const float* emb;          // [B][E] sinusoidal embedding saved by the forward
     const int64_t* y;          // labels or null
     const float* label_table;  // [classes][E]
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kThreads) void embed_bwd_weight_kernel(const EmbedB
             lv[u] = 0.f;
             if (a.n_labels > 0) {
                 const int64_t cls = a.y[a.n_labels == 1 ? 0 : b];
-                lv[u] = a.label_table[cls * E + e];
+                if (cls >= 0 && cls < a.n_classes) lv[u] = a.label_table[cls * E + e];   // out-of-range labels contribute nothing
             }
         }
 #pragma unroll
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(kThreads) void embed_bwd_weight_kernel(const EmbedB
 __global__ __launch_bounds__(kThreads) void embed_bwd_table_kernel(const EmbedBwd a) {
     const int b = blockIdx.x, E = a.emb_dim;
     const int64_t cls = a.y[a.n_labels == 1 ? 0 : b];
+    if (cls < 0 || cls >= a.n_classes) return;             // no row to add to
     for (int e = threadIdx.x; e < E; e += blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < 4; ++k) {
@@ -387,6 +388,8 @@ extern "C" int ddpm_time_embed_bwd(const ddpm_embed_bwd_args* a, void* stream) {
     d.batch = a->batch;
     d.emb_dim = a->emb_dim / 2 * 2;
     d.n_labels = a->n_labels;
+    d.n_classes = a->n_classes;
+    DDPM_REQUIRE(a->n_labels == 0 || a->n_classes > 0);
     d.emb = a->emb;
     d.y = a->y;
     d.label_table = a->label_table;

@@ -9,7 +9,7 @@ namespace {
 constexpr int kMaxEmb = 1024;
 
 struct EmbedDev {
-    int batch, emb_dim, n_labels, t_is_float;
+    int batch, emb_dim, n_labels, t_is_float, n_classes;
     const void* t;
     const int64_t* y;
     const float* label_table;
@@ -42,9 +42,12 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const EmbedDev a) {
         if (which == 0 && a.emb_out) a.emb_out[static_cast<int64_t>(b) * E + i] = v;
     }
     const bool has_label = a.n_labels > 0;
+    bool bad_label = false;
     if (has_label) {
         const int64_t cls = a.y[a.n_labels == 1 ? 0 : b];
-        for (int i = threadIdx.x; i < E; i += blockDim.x) lemb[i] = a.label_table[cls * E + i];
+        bad_label = cls < 0 || cls >= a.n_classes;      // never dereferenced: the outputs of this sample become NaN
+        if (!bad_label)
+            for (int i = threadIdx.x; i < E; i += blockDim.x) lemb[i] = a.label_table[cls * E + i];
     }
     __syncthreads();
     const int C = a.ch[which];
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const EmbedDev a) {
             for (int i = 0; i < E; ++i) l += lrow[i] * lemb[i];
             acc += l + lb[co];
         }
-        out[co] = acc;
+        out[co] = bad_label ? __builtin_nanf("") : acc;
     }
 }
 
@@ -103,7 +106,9 @@ extern "C" int ddpm_time_embed(const ddpm_embed_args* a, void* stream) {
     DDPM_REQUIRE(a && a->batch > 0 && a->t);
     DDPM_REQUIRE(a->emb_dim >= 4 && (a->emb_dim & 1) == 0 && a->emb_dim <= kMaxEmb);
     DDPM_REQUIRE(a->n_labels == 0 || a->n_labels == 1 || a->n_labels == a->batch);
+    DDPM_REQUIRE(a->n_labels == 0 || a->n_classes > 0);
     EmbedDev d;
+    d.n_classes = a->n_classes;
     d.batch = a->batch;
     d.emb_dim = a->emb_dim;
     d.n_labels = a->n_labels;

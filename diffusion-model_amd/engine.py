@@ -10,6 +10,7 @@ second-iteration/unet.py:118-158, third-iteration/unet.py:126-178.
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -274,10 +275,13 @@ class UNetEngine(TrainMixin):
             y = y.to(device=dev, dtype=torch.int64).contiguous()
             if y.numel() not in (1, B):
                 raise RuntimeError(f"label tensor of {y.numel()} entries cannot broadcast over a batch of {B}")
+            table = self.T("label_embedding.weight")
+            self._check_labels(y, table.shape[0])
             keep.append(y)
             a.n_labels = y.numel()
+            a.n_classes = table.shape[0]
             a.y = y.data_ptr()
-            a.label_table = self.T("label_embedding.weight").data_ptr()
+            a.label_table = table.data_ptr()
         else:
             a.n_labels = 0
         for k in range(4):
@@ -291,6 +295,18 @@ class UNetEngine(TrainMixin):
         a.emb_out = emb_out.data_ptr() if emb_out is not None else None
         call("ddpm_time_embed", C.byref(a), _stream())
         return outs
+
+    def _check_labels(self, y, n_classes):
+        """nn.Embedding raises for a label outside [0, num_classes) (third-iteration/unet.py:136); so does this, with
+        one device->host read per DISTINCT label tensor: the sampling loop hands the same tensor to every one of its
+        T steps and pays once. (The kernels never dereference such a label either way.)"""
+        seen = getattr(self, "_labels_ok", None)      # (weak reference to the tensor object, its version, class count)
+        if seen is not None and seen[0]() is y and seen[1:] == (y._version, n_classes):
+            return
+        lo, hi = torch.aminmax(y)
+        if int(lo) < 0 or int(hi) >= n_classes:
+            raise IndexError(f"label out of range: labels span [{int(lo)}, {int(hi)}], the embedding has {n_classes} classes")
+        self._labels_ok = (weakref.ref(y), y._version, n_classes)
 
     # ------------------------------------------------------------------ blocks (eval mode)
     def _act(self):

@@ -65,6 +65,7 @@ class TrainMixin:
         call("ddpm_bn_stats", raw.ptr, raw.ld, b * h * w, cout, BN_EPS, BN_MOMENTUM, _ptr(self._workspace(dev)), _ptr(mean),
              _ptr(invstd), _ptr(self.T(bn_key + ".running_mean")), _ptr(self.T(bn_key + ".running_var")), _stream())
         self._nbt.append(self.T(bn_key + ".num_batches_tracked"))    # incremented together at the end of the forward
+        self._stats_written += [self.T(bn_key + ".running_mean"), self.T(bn_key + ".running_var")]
         call("ddpm_bn_apply_fwd", raw.ptr, raw.ld, _ptr(mean), _ptr(invstd), _ptr(self.T(bn_key + ".weight")),
              _ptr(self.T(bn_key + ".bias")), residual.ptr if residual is not None else None,
              residual.ld if residual is not None else 0, _ptr(temb), act, out.ptr, out.ld, b, h * w, cout, _stream())
@@ -107,7 +108,7 @@ class TrainMixin:
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         fms = []
         tape = dict(x=x, t=t, y=y, emb=emb, shape=(B, H, W))
-        self._nbt = []
+        self._nbt, self._stats_written = [], []
 
         def buf(h, w, c):
             return torch.empty((B, h, w, c), device=dev, dtype=torch.float32)
@@ -169,7 +170,10 @@ class TrainMixin:
              _ptr(out), B, H, W, bc, self.cout_final, _stream())
         tape["final_in"] = hcur
         torch._foreach_add_(self._nbt, 1)
-        self._nbt = []
+        # the kernels updated the running statistics through raw pointers: tell torch (and the eval-mode cache of
+        # folded scale/shift pairs, which is keyed on tensor versions) that these buffers changed
+        torch.autograd.graph.increment_version(self._stats_written)
+        self._nbt, self._stats_written = [], []
         return out, [f.nchw() for f in fms], tape
 
     # ------------------------------------------------------------------ backward pieces
@@ -362,6 +366,7 @@ class TrainMixin:
         if y is not None:
             g.y = y.data_ptr()
             g.label_table = self.T("label_embedding.weight").data_ptr()
+            g.n_classes = self.T("label_embedding.weight").shape[0]
             outs["label_embedding.weight"] = torch.zeros_like(self.T("label_embedding.weight"))
             g.dlabel_table = outs["label_embedding.weight"].data_ptr()
         for k in range(4):

@@ -51,12 +51,15 @@ class _DiffusionBase:
             raise NotImplementedError("add_noise is not differentiable here (the training loop never needs it)")
         x0 = x_start.contiguous().float()
         nz = noise.to(x0.device).contiguous().float()
-        tt = t.to(device=x0.device, dtype=torch.int64).contiguous()
         B = x0.shape[0]
-        if tt.numel() != B:
-            raise RuntimeError(f"add_noise: {tt.numel()} timesteps for a batch of {B}")
-        if tt.numel() and (int(tt.max()) >= len(self._abar_h) or int(tt.min()) < -len(self._abar_h)):
+        if t.numel() != B:
+            raise RuntimeError(f"add_noise: {t.numel()} timesteps for a batch of {B}")
+        # Range check only where it is free (timesteps handed over on the host). Device timesteps are not read back:
+        # that would be a host sync in every training step; the kernel clamps the index, so an out-of-range device
+        # timestep reads a valid table entry instead of raising as the reference's CPU indexing would.
+        if not t.is_cuda and t.numel() and (int(t.max()) >= len(self._abar_h) or int(t.min()) < -len(self._abar_h)):
             raise IndexError("timestep out of range of the schedule")
+        tt = t.to(device=x0.device, dtype=torch.int64).contiguous()
         out = torch.empty_like(x0)
         call("ddpm_add_noise", _p(x0), _p(nz), _p(tt), _p(self._abar_on(x0.device)), len(self._abar_h), _p(out), B,
              x0.numel() // max(B, 1), _stream())

@@ -111,6 +111,10 @@ typedef struct ddpm_embed_args {
     int32_t emb_dim;        /* E (even, >= 4) */
     int32_t n_labels;       /* 0 = unconditional; 1 = one label broadcast over the batch; else B */
     int32_t t_is_float;     /* timesteps are fp32 instead of int64 */
+    int32_t n_classes;      /* rows of label_table (required when n_labels > 0). A label outside
+                               [0, n_classes) is never dereferenced: that sample's four output rows
+                               are filled with NaN (nn.Embedding raises there; a kernel cannot) */
+    int32_t reserved;
     const void* t;          /* device [B] int64 (or fp32) */
     const int64_t* y;       /* device [n_labels] or NULL */
     const float* label_table; /* device [num_classes][E] or NULL */
@@ -326,7 +330,9 @@ int ddpm_colsum_window(const float* x, int ld, int batch, int img_h, int img_w, 
 
 /* Backward of ddpm_time_embed w.r.t. the Linear / Embedding parameters. */
 typedef struct ddpm_embed_bwd_args {
-    int32_t batch, emb_dim, n_labels, reserved;
+    int32_t batch, emb_dim, n_labels;
+    int32_t n_classes;         /* rows of label_table / dlabel_table; samples whose label is outside
+                                  [0, n_classes) contribute nothing to the label-path gradients */
     const float* emb;          /* [B][E] saved sinusoidal embedding */
     const int64_t* y;
     const float* label_table;

@@ -228,7 +228,7 @@ def test_time_embed_fwd_bwd(n_labels):
 
     from diffusion_model_amd._lib import EmbedArgs
     a = EmbedArgs()
-    a.batch, a.emb_dim, a.n_labels, a.t_is_float = B, E, n_labels, 0
+    a.batch, a.emb_dim, a.n_labels, a.t_is_float, a.n_classes = B, E, n_labels, 0, ncls
     keep = [t.cuda(), y.cuda() if n_labels else None, table.detach().cuda()]
     a.t = keep[0].data_ptr()
     if n_labels:
@@ -248,7 +248,7 @@ def test_time_embed_fwd_bwd(n_labels):
     assert_close(embd.cpu(), emb, 2e-6, "emb")
 
     g = EmbedBwdArgs()
-    g.batch, g.emb_dim, g.n_labels = B, E, n_labels
+    g.batch, g.emb_dim, g.n_labels, g.n_classes = B, E, n_labels, ncls
     g.emb = embd.data_ptr()
     dtd = dev(dts)
     dW, dB = [torch.empty_like(v) for v in Wd], [torch.empty_like(v) for v in bd]
@@ -272,7 +272,7 @@ def test_time_embed_fwd_bwd(n_labels):
 
 
 @pytest.mark.parametrize("case", [(2, 49, 64, 8), (2, 196, 32, 4), (1, 784, 128, 16), (2, 64, 512, 64), (2, 100, 8, 1), (3, 33, 256, 32), (2, 196, 256, 32),
-                                  (1, 1024, 128, 16),
+                                  (1, 1024, 128, 16), (1, 4096, 64, 8), (1, 4096, 128, 16),
                                   # small maps: one workgroup per sample (forward up to 32 pixels, backward up to 49)
                                   (5, 9, 512, 64), (3, 16, 512, 64), (2, 32, 512, 64), (4, 1, 64, 8), (3, 25, 32, 4), (2, 32, 8, 1), (3, 49, 512, 64)])
 def test_attention_bwd(case):

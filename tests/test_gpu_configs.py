@@ -58,6 +58,23 @@ def test_colour_64x64_eval_and_gradients():
     assert worst[0][0] <= 1.0, worst[:6]
 
 
+def test_colour_64x64_full_width_eval():
+    """The roofline-stress configuration at its real width: (3,3,64,128,num_classes=10) on 3x64x64. Attention runs at
+    N = 4096 with 64 and 128 channels and at N = 1024 with 256 (the split-bf16 kernels), and at N = 256 with 512
+    channels; eps-hat and all seven feature maps against the CPU oracle."""
+    m = build(3, 3, 64, 128, 13, classes=10).eval()
+    sd = cpu_sd(m)
+    x = seeded_tensor((2, 3, 64, 64), 3, "x")
+    t = torch.tensor([801, 12])
+    y = torch.tensor([7, 0])
+    with torch.no_grad():
+        out = m(x.cuda(), t.cuda(), y.cuda())
+        want, fms, _ = O.unet_forward(sd, 3, x, t, y, train=False)
+    assert_close(out.cpu(), want, 5e-5, "64x64 full-width eval eps")
+    for i, fm in enumerate(m.feature_maps):
+        assert_close(fm.cpu(), fms[i], 5e-5, f"64x64 full-width eval fm{i}")
+
+
 def test_colour_32x32_full_width_train_step():
     """(3,3,64,128) on 3x32x32: loss and every parameter gradient of one eps-MSE step.
 

@@ -114,3 +114,37 @@ def test_adam_host_side_contract():
     p[0].grad = torch.zeros(4)
     with pytest.raises(RuntimeError):        # CPU parameters have no path
         ours.step()
+
+
+@pytest.mark.parametrize("iteration", ["first-iteration", "second-iteration", "3"])
+def test_launcher_runs_an_unchanged_script_on_the_drop_ins(tmp_path, iteration):
+    """A script that sits NEXT TO modules named unet / diffusion / beta_scheduler / embeddings (as the reference's
+    entry scripts do, first-iteration/main.py:6-9) and is started through the launcher must get the package's
+    classes, not its neighbours (which Python would pick if the script were started directly)."""
+    import subprocess
+    import sys
+    for name in ("unet", "diffusion", "beta_scheduler", "embeddings"):
+        (tmp_path / f"{name}.py").write_text("raise SystemExit('decoy module imported: ' + __name__)\n")
+    (tmp_path / "utils.py").write_text("MARK = 'script-dir utils'\n")
+    (tmp_path / "main.py").write_text(
+        "import sys\n"
+        "from unet import UNet\n"
+        "from diffusion import DiffusionModel\n"
+        "from beta_scheduler import BetaScheduler\n"
+        "from embeddings import SinusoidalTimeEmbedding\n"
+        "from utils import MARK\n"
+        "assert __name__ == '__main__'\n"
+        "print(UNet.__module__, DiffusionModel.__module__, BetaScheduler.__module__, SinusoidalTimeEmbedding.__module__)\n"
+        "print(MARK, '|', ' '.join(sys.argv[1:]), '|', UNet._variant)\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "diffusion_model_amd.run", iteration, "main.py", "--epochs", "2"], cwd=tmp_path, env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    mods, rest = r.stdout.strip().splitlines()
+    assert all(m.startswith("diffusion_model_amd.") for m in mods.split()), mods
+    want_variant = {"first-iteration": 1, "second-iteration": 2, "3": 3}[iteration]
+    assert rest == f"script-dir utils | --epochs 2 | {want_variant}"
+    # started directly (what the old recipe did), the same script picks up its neighbours
+    r = subprocess.run([sys.executable, "main.py"], cwd=tmp_path, capture_output=True, text=True,
+                       env=dict(env, PYTHONPATH=os.path.join(ROOT, "diffusion-model_amd", "drop_in", "first-iteration")))
+    assert r.returncode != 0 and "decoy module imported" in r.stderr
