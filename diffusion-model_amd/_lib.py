@@ -59,6 +59,8 @@ _SIGNATURES = {
     "ddpm_pool_skip_fwd": [P, I32, P, P, I32, P, I32, P, I32, I32, I32, I32, P],
     "ddpm_add_temb": [P, I32, P, P, I32, I32, I32, I32, P],
     "ddpm_bn_stats": [P, I32, I64, I32, F32, F32, P, P, P, P, P, P],
+    "ddpm_bn_stats_noalloc_max_channels": [],
+    "ddpm_bn_stats_noalloc": [P, I32, I64, I32, F32, F32, P, P, P, P, P],
     "ddpm_bn_apply_fwd": [P, I32, P, P, P, P, P, I32, P, I32, P, I32, I32, I32, I32, P],
     "ddpm_bn_bwd": [P, I32, P, I32, P, I32, P, P, P, P, I32, I64, I32, P, P, P, P, I32, P, I32, P, I32, P, P],
     "ddpm_colsum": [P, I32, I32, I64, I32, P, I32, P, P],

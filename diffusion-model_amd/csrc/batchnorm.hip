@@ -7,6 +7,8 @@
 //   backward: dz = dout * act'(z)             z = (x-mean)*invstd*w + b [+ residual]
 //             dw = sum dz*xhat, db = sum dz
 //             dx = w*invstd * (dz - db/M - xhat*dw/M),   dresidual = dz
+#include <mutex>
+
 #include "common.h"
 
 using ddpm::as_stream;
@@ -366,6 +368,66 @@ extern "C" int ddpm_bn_stats(const float* x, int ldx, int64_t rows, int c, float
     bn_stats_final_kernel<<<(c + kFin - 1) / kFin, kThreads, 0, as_stream(stream)>>>(workspace, nb, rows, c, eps, momentum, mean,
                                                                                              invstd, running_mean, running_var);
     return ddpm::check_launch("bn_stats");
+}
+
+// ---- allocation-free variant of ddpm_bn_stats -------------------------------------------------
+// The per-block partial sums live in a file-scope device array instead of a caller workspace, for
+// callers that cannot allocate device memory (code under HIP graph capture, serving loops, harnesses
+// that forbid hipMalloc). Every GPU holds its own copy of the array at its own address; the host
+// looks that address up once per device and passes it to the kernels like any other workspace.
+constexpr int kNoAllocMaxChannels = 512;
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) double scratch[static_cast<size_t>(kMaxPartialBlocks) * 2 * kNoAllocMaxChannels];   // 8 MiB
+
+namespace {
+double* g_scratch_ptr[kMaxDevices];      // device address of `scratch` on each GPU (null until first use there)
+std::mutex g_scratch_mutex;
+
+// Device address of this GPU's copy of `scratch`, looked up on the first call on that device.
+int scratch_for_current_device(double** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        ddpm::set_error("ddpm_bn_stats_noalloc: cannot identify the current device (%s, device %d, at most %d supported)",
+                        hipGetErrorString(e), dev, kMaxDevices);
+        return DDPM_E_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            ddpm::set_error("ddpm_bn_stats_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return DDPM_E_LAUNCH;
+        }
+        g_scratch_ptr[dev] = static_cast<double*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return DDPM_OK;
+}
+}  // namespace
+
+extern "C" int ddpm_bn_stats_noalloc_max_channels(void) { return kNoAllocMaxChannels; }
+
+extern "C" int ddpm_bn_stats_noalloc(const float* x, int ldx, int64_t rows, int c, float eps, float momentum, float* mean, float* invstd,
+                                     float* running_mean, float* running_var, void* stream) {
+    DDPM_REQUIRE(x && mean && invstd && rows > 0 && c > 0 && (c & 3) == 0);
+    if (c > kNoAllocMaxChannels) {
+        ddpm::set_error("ddpm_bn_stats_noalloc: %d channels exceed the %d its built-in scratch buffer holds; use ddpm_bn_stats with a "
+                        "caller workspace", c, kNoAllocMaxChannels);
+        return DDPM_E_INVALID;
+    }
+    DDPM_REQUIRE((ldx & 3) == 0 && ldx >= c && ddpm::aligned16(x) && ddpm::aligned16(mean) && ddpm::aligned16(invstd));
+    DDPM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    double* ws = nullptr;
+    if (int rc = scratch_for_current_device(&ws)) return rc;
+    // every partial slot that the finishing kernel reads is written by the first kernel of this call
+    // (nb blocks x 2 x c), so nothing left over from an earlier, larger call is ever read: no clearing needed
+    const int nb = partial_blocks(rows, c);
+    bn_stats_partial_kernel<<<nb, kThreads, 0, as_stream(stream)>>>(x, ldx, rows, c, ws);
+    bn_stats_final_kernel<<<(c + kFin - 1) / kFin, kThreads, 0, as_stream(stream)>>>(ws, nb, rows, c, eps, momentum, mean, invstd,
+                                                                                             running_mean, running_var);
+    return ddpm::check_launch("bn_stats_noalloc");
 }
 
 extern "C" int ddpm_bn_apply_fwd(const float* x, int ldx, const float* mean, const float* invstd, const float* w, const float* b,

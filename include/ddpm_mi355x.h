@@ -265,6 +265,20 @@ int ddpm_bn_stats(const float* x, int ldx, int64_t rows, int c, float eps, float
                   double* workspace, float* mean, float* invstd, float* running_mean,
                   float* running_var, void* stream);
 
+/* ddpm_bn_stats without a workspace argument and without any allocation. No counterpart in the
+ * reference: it exists for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc). The per-block partial sums go to
+ * a buffer built into the library's device image (8 MiB per GPU, held until the process ends),
+ * which limits c to ddpm_bn_stats_noalloc_max_channels() = 512; a larger c returns DDPM_E_INVALID.
+ * Results are bit-identical to ddpm_bn_stats. All calls on one GPU share that buffer: calls that
+ * overlap on the same GPU (different streams or threads) race; calls ordered on one stream do not.
+ * The first call on a device looks the buffer's address up (hipGetSymbolAddress) and should be made
+ * outside a stream capture. */
+int ddpm_bn_stats_noalloc_max_channels(void);
+int ddpm_bn_stats_noalloc(const float* x, int ldx, int64_t rows, int c, float eps, float momentum,
+                          float* mean, float* invstd, float* running_mean, float* running_var,
+                          void* stream);
+
 /* out = act((x-mean)*invstd*w + b [+ residual]) [+ temb[b][c]] */
 int ddpm_bn_apply_fwd(const float* x, int ldx, const float* mean, const float* invstd, const float* w,
                       const float* b, const float* residual, int ldr, const float* temb, int act,
