@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the DDPM hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload train|sample] [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--workload both|train|sample|train_color|sample_64] [--batch B]
 
 One "step" is one pass of the hot path over one batch of synthetic input:
-  train  (default; BASELINE.json configs[1]): the body of the reference's training loop
+  train  (BASELINE.json configs[1]): the body of the reference's training loop
          (first-iteration/main.py:65-87) -- noise + timestep draw, forward noising, UNet train-mode
          forward, eps-MSE, backward, Adam step, loss.item() -- second-iteration UNet (1,1,64,128),
          1x28x28, batch 256 per GPU. value = train samples/s.
-  sample (BASELINE.json configs[2]): one ancestral denoising step at batch B per GPU (UNet eval
+  sample (BASELINE.json configs[2]): one ancestral denoising step at batch 512 per GPU (UNet eval
          forward, noise draw, fused reverse-step kernel), third-iteration UNet, 1x32x32. The metric,
-         sampled images/s over the full T=1000-step loop, is B_total / (1000 * seconds per step).
+         sampled images/s over the full T=1000-step loop, is B_total / (1000 * seconds per step); a
+         real DiffusionModel.sample() call (T=50 schedule) is timed next to it to show that the
+         call costs T times the step.
+The default (--workload both) measures BOTH halves of the metric, K timed steps each: the JSON
+line's top-level fields are the training half, its "sampling" object the sampling half.
 For N > 1 the batch axis is sharded (weak scaling: per-GPU batch fixed): no data-path collective for
-sampling; an RCCL all-reduce (average) of the flattened gradients per training step.
-Prints ONE JSON line on rank 0.
+sampling; RCCL all-reduces of gradient buckets (launched while the backward is still running) per
+training step. Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import platform
 import sys
 import time
 
@@ -34,6 +39,7 @@ BF16_MFMA_PEAK_TFLOPS = 2516.6    # gfx950 dense bf16 matrix peak (v_mfma_f32_32
 SPLIT_PRODUCTS = 6                # bf16 MFMA products per fp32 product in the split-bf16 kernels
 HBM_PEAK_GBPS = 8000.0            # HBM3E peak of one MI355X
 SUSTAINED_BF16_TFLOPS = 1900.0    # measured: pure-MFMA loop, two waves per SIMD (tools/probe/mfma_power.hip)
+T_FULL = 1000
 
 
 def kernel_peak(label):
@@ -42,7 +48,6 @@ def kernel_peak(label):
         return BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
     return FP32_MFMA_PEAK_TFLOPS
 
-T_FULL = 1000
 
 WORKLOADS = {
     "train": dict(name="configs[1]: second-iteration UNet (1,1,64,128), MNIST-shaped 1x28x28, batch 256 training step "
@@ -71,11 +76,21 @@ def build_model(variant, cin, labels):
     return m
 
 
+def log(msg, trace=False):
+    """Progress on stderr (stdout carries exactly one JSON line). trace messages (every rank) only
+    when DDPM_BENCH_TRACE=<seconds> is set, which also arms a stack dump after that many seconds."""
+    if trace:
+        if not os.environ.get("DDPM_BENCH_TRACE"):
+            return
+    elif int(os.environ.get("RANK", "0")) != 0:
+        return
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def reverse_step_bandwidth(dev, loop_elements, big=1 << 26, iters=20):
     """The fused reverse-step kernel (x_{t-1} from x_t, eps-hat, z: 16 algorithmic bytes per element) against the HBM
     peak, timed with HIP events outside the timed steps: at 2^26 elements, where every operand comes from HBM, and at
     the size one denoising step of this workload launches it with (small enough to stay in the caches)."""
-    import ctypes as C
     from diffusion_model_amd._lib import call
     res = {"kernel": "reverse_step", "bytes_per_element": 16, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
     for tag, n in (("hbm_resident", big), ("loop_size", loop_elements)):
@@ -98,14 +113,28 @@ def reverse_step_bandwidth(dev, loop_elements, big=1 << 26, iters=20):
     return res
 
 
-def cpu_baseline(workload, wl, seconds=12.0):
-    """The CPU oracle (a torch-CPU restatement of the reference) timed on the host cores, bounded sample."""
+def host_description():
+    model = platform.processor() or "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model
+
+
+def cpu_baseline(workload, wl, batch, min_steps=3, seconds=8.0):
+    """The CPU oracle (a torch-CPU restatement of the reference) timed on the host cores at the workload's own batch:
+    at least `min_steps` steps and at least `seconds` seconds."""
     from oracle import ddpm_oracle as O
     m = build_model(wl["variant"], wl["cin"], wl["labels"])
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     betas = O.schedule_betas("linear", T_FULL)
     alphas, abar = O.schedule_tables(betas)
-    B, cin, hw = 8, wl["cin"], wl["hw"]
+    B, cin, hw = batch, wl["cin"], wl["hw"]
+    common = dict(cores=torch.get_num_threads(), kind="port", cpu=host_description(), torch=torch.__version__, batch=B)
     n, t0 = 0, time.time()
     if workload.startswith("sample"):
         x = torch.randn(B, cin, hw, hw)
@@ -113,16 +142,16 @@ def cpu_baseline(workload, wl, seconds=12.0):
         y = torch.tensor([3]) if wl["labels"] else None
         c = O.step_coefficients(betas, alphas, abar, 500)
         with torch.no_grad():
-            while n < 2 or time.time() - t0 < seconds:
+            while n < min_steps or time.time() - t0 < seconds:
                 eps = O.unet_forward(sd, wl["variant"], x, t, y, train=False)[0]
                 x = torch.from_numpy(O.reverse_step(x.numpy(), eps.numpy(), torch.randn_like(x).numpy(), *c))
                 n += 1
         dt = (time.time() - t0) / n
-        return dict(value=B / (T_FULL * dt), unit="images/s", cores=torch.get_num_threads(), kind="port",
-                    sample=f"{n} denoising steps of the CPU oracle at batch {B}, extrapolated to the {T_FULL}-step loop")
+        return dict(value=round(B / (T_FULL * dt), 5), unit="images/s", **common,
+                    sample=f"{n} denoising steps of the CPU oracle at batch {B} ({dt:.2f} s each), extrapolated to the {T_FULL}-step loop")
     params = {k: v.clone() for k, v in sd.items() if O.is_param(k)}
     state, cur = {}, dict(sd)
-    while n < 2 or time.time() - t0 < seconds:
+    while n < min_steps or time.time() - t0 < seconds:
         x0, noise = torch.rand(B, cin, hw, hw) * 2 - 1, torch.randn(B, cin, hw, hw)
         t = torch.randint(0, T_FULL, (B,))
         noisy = torch.from_numpy(O.add_noise(x0.numpy(), noise.numpy(), t.numpy(), abar))
@@ -132,19 +161,236 @@ def cpu_baseline(workload, wl, seconds=12.0):
         O.adam_step(params, grads, state)
         n += 1
     dt = (time.time() - t0) / n
-    return dict(value=B / dt, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} training steps of the CPU oracle (torch-CPU autograd + Adam) at batch {B}")
+    return dict(value=round(B / dt, 3), unit="samples/s", **common,
+                sample=f"{n} training steps of the CPU oracle (torch-CPU autograd + Adam) at batch {B} ({dt:.2f} s each)")
 
 
-def log(msg, trace=False):
-    """Progress on stderr (stdout carries exactly one JSON line). trace messages (every rank) only
-    when DDPM_BENCH_TRACE=<seconds> is set, which also arms a stack dump after that many seconds."""
-    if trace:
-        if not os.environ.get("DDPM_BENCH_TRACE"):
+class Job:
+    """One workload on this rank: model, the step function, and what the measurement collects."""
+
+    def __init__(self, workload, args, ctx):
+        import diffusion_model_amd as pkg
+        from diffusion_model_amd import parallel
+        from diffusion_model_amd._lib import call
+        from diffusion_model_amd.schedule import step_coefficients_host
+        self.workload, self.args, self.ctx = workload, args, ctx
+        self.wl = wl = WORKLOADS[workload]
+        dev, rank = ctx["dev"], ctx["rank"]
+        self.B = B = args.batch or wl["batch"]
+        self.shape = shape = (B, wl["cin"], wl["hw"], wl["hw"])
+        self.model = model = build_model(wl["variant"], wl["cin"], wl["labels"]).to(dev)
+        betas = pkg.BetaScheduler(T_FULL, device=dev).get_schedule("linear")
+        self.dm = dm = pkg.make_diffusion_class(wl["variant"])(model, betas, T_FULL)
+        gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.sampling = workload.startswith("sample")
+        self.state = state = {}
+        self.reducer = None
+        if self.sampling:
+            model.eval()
+            self.labels = labels = torch.tensor([3], device=dev) if wl["labels"] else None
+            state.update(x=torch.randn(shape, generator=gen).to(dev), t=T_FULL - 1)
+
+            def one_step():
+                """Body of the sampling loop for one timestep (third-iteration/diffusion.py:24-44)."""
+                x, t = state["x"], state["t"]
+                with torch.no_grad():
+                    tt = torch.full((B,), t, dtype=torch.long, device=dev)
+                    eps = model(x, tt, labels) if wl["variant"] == 3 else model(x, tt)
+                    c1, c2, c3 = step_coefficients_host(dm._betas_h[t], dm._alphas_h[t], dm._abar_h[t])
+                    z = torch.randn_like(x)
+                    out = torch.empty_like(x)
+                    call("ddpm_reverse_step", C.c_void_p(x.data_ptr()), C.c_void_p(eps.data_ptr()), None, 0.0, C.c_void_p(z.data_ptr()),
+                         c1, c2, c3, C.c_void_p(out.data_ptr()), x.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                state["x"], state["t"] = out, (t - 1 if t > 1 else T_FULL - 1)
+        else:
+            model.train()
+            from diffusion_model_amd.optim import Adam
+            opt = (torch.optim.Adam if args.optimizer == "torch" else Adam)(model.parameters(), lr=2e-4)
+            crit = torch.nn.MSELoss()
+            data = (torch.rand(shape, generator=gen) * 2 - 1).to(dev)            # synthetic image batch in [-1, 1]
+            params = [p for p in model.parameters()]
+            state["loss"] = 0.0
+
+            def one_step():
+                """Body of the reference's training loop (first-iteration/main.py:65-87)."""
+                x = data
+                noise = torch.randn_like(x)
+                timesteps = torch.randint(0, T_FULL, (B,), device=dev)
+                noisy = dm.add_noise(x, noise, timesteps)
+                pred = model(noisy, timesteps)
+                loss = crit(pred, noise)
+                opt.zero_grad()
+                loss.backward()
+                if ctx["dist"] is not None:                                      # data-parallel: average gradients over ranks
+                    if self.reducer is not None:
+                        self.reducer.finish()                                    # buckets were launched during the backward
+                    else:
+                        parallel.average_gradients(params)
+                opt.step()
+                state["loss"] = loss.item()
+        self.one_step = one_step
+        self.prof = None
+
+    # ---- phases -------------------------------------------------------------------------------
+    def prepass(self):
+        """Per-kernel HIP events for the multi-GPU case, taken BEFORE the process group exists (2 steps, no
+        collective), so that event recording never interleaves with RCCL traffic in the timed region."""
+        self.one_step()
+        self.model._engine.prof = []
+        self.one_step()
+        self.one_step()
+        torch.cuda.synchronize()
+        self.prof = self.model._engine.prof
+        self.model._engine.prof = None
+
+    def attach_distributed(self):
+        from diffusion_model_amd import parallel
+        if self.ctx["dist"] is None:
             return
-    elif int(os.environ.get("RANK", "0")) != 0:
-        return
-    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+        parallel.broadcast_parameters(self.model)
+        if not self.sampling and self.args.allreduce == "bucketed":
+            self.reducer = parallel.BucketedGradientAverager(self.model, bucket_bytes=self.args.bucket_mb << 20)
+            self.reducer.attach()
+        if not self.sampling and self.args.batchnorm == "sync":
+            self.model._engine.sync_bn = True
+
+    def settle(self):
+        # Settling steps before the W warm-up steps: the first second of a process holds one-off host stalls
+        # (first-use initialisation inside the HIP runtime and the caching allocator: a single step of the first
+        # dozen takes 50-80 ms instead of 29), which would otherwise land inside a short timed region.
+        args, multi = self.args, self.ctx["multi"]
+        n = 0
+        if multi:     # every rank must issue the same number of collectives: a fixed count instead of a time budget
+            for _ in range(int(round(args.settle * 30))):
+                self.one_step()
+                n += 1
+        else:
+            t_end = time.perf_counter() + args.settle
+            while time.perf_counter() < t_end:
+                self.one_step()
+                n += 1
+        torch.cuda.synchronize()
+        return n
+
+    def timed(self, barrier):
+        args, multi = self.args, self.ctx["multi"]
+        for _ in range(args.warmup):
+            self.one_step()
+        if not multi:
+            self.model._engine.prof = []
+            self.model._engine.prof_stride = max(1, args.profile_stride)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            self.one_step()
+            log(f"rank {self.ctx['rank']}: step {i} issued", True)
+        barrier()
+        dt = time.perf_counter() - t0
+        if not multi:
+            self.prof = self.model._engine.prof
+            self.model._engine.prof = None
+        if self.sampling:
+            assert torch.isfinite(self.state["x"]).all()
+        else:
+            assert self.state["loss"] == self.state["loss"], "loss is NaN"
+        return dt
+
+    def full_call(self, T=50):
+        """One real DiffusionModel.sample() call (its own T-step schedule, the ten stage copies to the host included),
+        wall clock: T denoising steps must cost T times the timed step."""
+        import diffusion_model_amd as pkg
+        dev = self.ctx["dev"]
+        betas = pkg.BetaScheduler(T, device=dev).get_schedule("linear")
+        dm = pkg.make_diffusion_class(self.wl["variant"])(self.model, betas, T)
+        kw = dict(labels=self.labels) if self.wl["variant"] == 3 else {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            stages = dm.sample(self.shape, dev, **kw)
+        dt = time.perf_counter() - t0
+        assert len(stages) == 10 and stages[-1][1] == 0 and torch.isfinite(stages[-1][0]).all()
+        return dict(T=T, seconds=round(dt, 4), ms_per_step=round(dt / T * 1e3, 3), stages=len(stages),
+                    what="DiffusionModel.sample(x_shape, device, labels) of a T=50 linear schedule at this batch, wall clock "
+                         "including the ten stage copies to pinned host memory")
+
+    # ---- report -------------------------------------------------------------------------------
+    def report(self, dt):
+        args, ctx, wl = self.args, self.ctx, self.wl
+        world, multi = ctx["world"], ctx["multi"]
+        sec_per_step = dt / args.steps
+        total_b = self.B * world
+        value = total_b / (T_FULL * sec_per_step) if self.sampling else total_b / sec_per_step
+        agg = {}
+        for label, flops, e0, e1 in self.prof:
+            a = agg.setdefault(label, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        if os.environ.get("DDPM_BENCH_PER_SHAPE") and ctx["rank"] == 0:   # diagnostic: the same figures per distinct launch shape
+            shapes = {}
+            for label, flops, e0, e1 in self.prof:
+                a = shapes.setdefault((label, flops), [0.0, 0])
+                a[0] += e0.elapsed_time(e1) * 1e-3
+                a[1] += 1
+            for (label, flops), (t, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
+                log(f"  {label:40s} {flops / 1e9:9.2f} GFLOP  x{n:3d}  {t / n * 1e6:8.1f} us  {flops * n / t / 1e12:6.1f} TFLOP/s")
+        if not agg:
+            sys.exit(f"no MFMA launch was sampled: lower --profile-stride ({sec_per_step * 1e3:.3f} ms/step)")
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        achieved = dom[1][0] / dom[1][1] / 1e12
+        # launches are sampled 1 in `stride` (all of them in the multi-GPU pre-pass): scale the summed time back up
+        prof_steps = args.steps / max(1, args.profile_stride) if not multi else 2
+        kernels = {k: dict(sampled_launches=v[2], avg_ms=round(v[1] / v[2] * 1e3, 4), tflops=round(v[0] / v[1] / 1e12, 2),
+                           peak_tflops=round(kernel_peak(k), 1), frac=round(v[0] / v[1] / 1e12 / kernel_peak(k), 4),
+                           share_of_step=round(v[1] / prof_steps / sec_per_step, 3)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+        cfg = {"workload": wl["name"], "per_gpu_batch": self.B, "global_batch": total_b}
+        if self.sampling:
+            cfg.update(T=T_FULL, step="one denoising step (UNet eval forward + noise draw + fused reverse-step kernel); "
+                                      "images/s = global_batch / (T * seconds_per_step)")
+        else:
+            bn = "global batch statistics (all-reduce of per-rank sums, forward and backward)" if (multi and args.batchnorm == "sync") \
+                else "per-rank batch statistics"
+            par = "single GPU"
+            if multi:
+                backend = "RCCL" if args.backend == "nccl" else args.backend
+                par = (f"dp{world}: {backend} all-reduce of {args.bucket_mb} MiB gradient buckets launched from inside the backward"
+                       if args.allreduce == "bucketed" else f"dp{world}: {backend} all-reduce of the flattened gradients after the backward")
+            cfg.update(optimizer=("torch.optim.Adam(lr=2e-4)" if args.optimizer == "torch" else
+                                  "Adam(lr=2e-4), torch.optim.Adam's update as one HIP launch per 64 tensors"),
+                       batchnorm=bn, parallelism=par, last_loss=round(self.state["loss"], 5))
+        # memory-side bytes per launch of the dominant kernel: not measurable live (hardware counters need their own
+        # rocprofv3 --pmc passes), so taken from the newest committed summary of tools/pmc_traffic.sh for this workload
+        traffic, traffic_src = None, None
+        kernel_symbol = {"conv3x3_halo<split-bf16>": "conv3x3_halo_kernel", "attention_fwd<split-bf16>": "attention_fwd_x3_kernel"}.get(dom[0])
+        kind = "sample" if self.workload == "sample" else "train"
+        tfile = next((f for f in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_{kind}.txt") for r in (3, 2, 1)) if os.path.exists(f)), None)
+        if kernel_symbol and self.workload in ("train", "sample") and tfile:
+            for line in open(tfile):
+                f = line.split()
+                if len(f) > 4 and kernel_symbol in line and f[0].isdigit():
+                    traffic = int(float(f[3]) * 1e6)
+                    traffic_src = ("bytes per launch, mean over this kernel's launches of one step: rocprofv3 --pmc FETCH_SIZE (x 2, the gfx950 "
+                                   "correction for wide loads) + WRITE_SIZE in separate passes, profiles/" + os.path.basename(tfile))
+                    break
+        split = "split-bf16" in dom[0]
+        return {
+            "metric": wl["metric"], "value": round(value, 4), "unit": wl["unit"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": cfg,
+            "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(kernel_peak(dom[0]), 1),
+                         "unit": "TFLOP/s", "frac": round(achieved / kernel_peak(dom[0]), 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "sustained_peak": (round(SUSTAINED_BF16_TFLOPS / SPLIT_PRODUCTS, 1) if split else None),
+                         "sustained_peak_note": "a loop of nothing but independent v_mfma_f32_32x32x16_bf16 (tools/probe/mfma_power.hip) "
+                                                "sustains 1.9 PFLOP/s on this chip (1.8 GHz under that load, not the 2.4 GHz of the nominal peak)",
+                         "arithmetic": ("fp32 operands split exactly into 3 bf16 terms, 6 cross products per fp32 product on "
+                                        "v_mfma_f32_32x32x16_bf16 with fp32 accumulation: achieved/peak count algorithmic fp32 FLOP, "
+                                        "peak = bf16 dense peak / 6" if split else "v_mfma_f32_32x32x2_f32"),
+                         "avg_launch_ms": round(dom[1][1] / dom[1][2] * 1e3, 4), "sampled_launches": dom[1][2],
+                         "measured": f"HIP events around every {max(1, args.profile_stride)}-th MFMA launch of the timed steps (rotating over the launch sites)"
+                                     if not multi else "HIP events in a 2-step pre-pass before the process group is created"},
+            "kernels": kernels,
+        }
 
 
 def main():
@@ -152,13 +398,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="train", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="both", choices=["both"] + list(WORKLOADS),
+                    help="both (default) = train (the line's top level) + sample (its \"sampling\" object)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--optimizer", default="hip", choices=["hip", "torch"], help="training: diffusion_model_amd.optim.Adam or torch.optim.Adam")
     ap.add_argument("--profile-stride", type=int, default=7,
                     help="bracket every N-th MFMA launch of the timed steps with HIP events (1 = all; events cost GPU time)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--allreduce", default="flat", choices=["bucketed", "flat"],
+                    help="data-parallel training: gradient buckets all-reduced while the backward runs, or one flat all-reduce after it")
+    ap.add_argument("--bucket-mb", type=int, default=8, help="gradient bucket size in MiB (bucketed all-reduce)")
+    ap.add_argument("--batchnorm", default="local", choices=["local", "sync"],
+                    help="data-parallel training: per-rank batch statistics, or global ones (the reference's semantics at the global batch)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--settle", type=float, default=1.5, help="seconds of untimed steps before the warm-up steps")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the multi-GPU code path (process group, collectives) "
@@ -174,78 +426,22 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
     multi = world > 1 or args.force_dist
+    ctx = dict(dev=dev, world=world, rank=rank, local=local, multi=multi, dist=None)
     log(f"world={world} device={dev} workload={args.workload}")
     if os.environ.get("DDPM_BENCH_TRACE"):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DDPM_BENCH_TRACE"]), exit=True)
-    import diffusion_model_amd as pkg
     from diffusion_model_amd import parallel
-    from diffusion_model_amd._lib import call
-    from diffusion_model_amd.schedule import step_coefficients_host
-    wl = WORKLOADS[args.workload]
-    B = args.batch or wl["batch"]
-    shape = (B, wl["cin"], wl["hw"], wl["hw"])
-    model = build_model(wl["variant"], wl["cin"], wl["labels"]).to(dev)
-    betas = pkg.BetaScheduler(T_FULL, device=dev).get_schedule("linear")
-    dm = pkg.make_diffusion_class(wl["variant"])(model, betas, T_FULL)
-    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
 
-    if args.workload.startswith("sample"):
-        model.eval()
-        labels = torch.tensor([3], device=dev) if wl["labels"] else None
-        state = {"x": torch.randn(shape, generator=gen).to(dev), "t": T_FULL - 1}
-
-        def one_step():
-            """Body of the sampling loop for one timestep (third-iteration/diffusion.py:24-44)."""
-            x, t = state["x"], state["t"]
-            with torch.no_grad():
-                tt = torch.full((B,), t, dtype=torch.long, device=dev)
-                eps = model(x, tt, labels) if wl["variant"] == 3 else model(x, tt)
-                c1, c2, c3 = step_coefficients_host(dm._betas_h[t], dm._alphas_h[t], dm._abar_h[t])
-                z = torch.randn_like(x)
-                out = torch.empty_like(x)
-                call("ddpm_reverse_step", C.c_void_p(x.data_ptr()), C.c_void_p(eps.data_ptr()), None, 0.0, C.c_void_p(z.data_ptr()),
-                     c1, c2, c3, C.c_void_p(out.data_ptr()), x.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
-            state["x"], state["t"] = out, t - 1
-    else:
-        model.train()
-        from diffusion_model_amd.optim import Adam
-        opt = (torch.optim.Adam if args.optimizer == "torch" else Adam)(model.parameters(), lr=2e-4)
-        crit = torch.nn.MSELoss()
-        data = (torch.rand(shape, generator=gen) * 2 - 1).to(dev)            # synthetic MNIST-shaped batch in [-1, 1]
-        params = [p for p in model.parameters()]
-        state = {"loss": 0.0}
-
-        def one_step():
-            """Body of the reference's training loop (first-iteration/main.py:65-87)."""
-            x = data
-            noise = torch.randn_like(x)
-            timesteps = torch.randint(0, T_FULL, (B,), device=dev)
-            noisy = dm.add_noise(x, noise, timesteps)
-            pred = model(noisy, timesteps)
-            loss = crit(pred, noise)
-            opt.zero_grad()
-            loss.backward()
-            if dist is not None and not os.environ.get("DDPM_BENCH_SKIP_ALLREDUCE"):   # data-parallel: average gradients over ranks
-                parallel.average_gradients(params)
-            elif os.environ.get("DDPM_BENCH_FLAT_GRADS"):                    # diagnostic: gradients as views of one buffer
-                gs = [p for p in params if p.grad is not None]
-                flat = torch.cat([p.grad.reshape(-1) for p in gs])
-                off = 0
-                for p in gs:
-                    n = p.grad.numel()
-                    p.grad = flat[off:off + n].view_as(p.grad)
-                    off += n
-            opt.step()
-            if os.environ.get("DDPM_BENCH_DEFER_LOSS"):                      # diagnostic: no host sync inside the step
-                state["loss_t"] = loss
-            else:
-                state["loss"] = loss.item()
+    names = ["train", "sample"] if args.workload == "both" else [args.workload]
+    if args.workload == "both" and args.batch:
+        sys.exit("--batch needs a single --workload")
+    jobs = [Job(n, args, ctx) for n in names]
 
     def barrier():
         torch.cuda.synchronize()
+        dist = ctx["dist"]
         if dist is not None:
             log(f"rank {rank}: entering barrier", True)
             if args.backend == "nccl":
@@ -255,18 +451,10 @@ def main():
             torch.cuda.synchronize()
             log(f"rank {rank}: left barrier", True)
 
-    prof = None
     if multi:
-        # Per-kernel HIP events are taken in a pre-pass BEFORE the process group exists (2 steps, no
-        # collective), so that event recording never interleaves with RCCL traffic in the timed region.
         log("multi-GPU: profiling pre-pass (no collectives)")
-        one_step()
-        model._engine.prof = []
-        one_step()
-        one_step()
-        torch.cuda.synchronize()
-        prof, prof_dt = model._engine.prof, None
-        model._engine.prof = None
+        for j in jobs:
+            j.prepass()
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -276,128 +464,46 @@ def main():
             dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist_mod.init_process_group(args.backend, rank=rank, world_size=world)
-        dist = dist_mod
-        if dist is not None:
-            parallel.broadcast_parameters(model)
+        ctx["dist"] = dist_mod
+        for j in jobs:
+            j.attach_distributed()
 
-    # Settling steps before the W warm-up steps: the first second of a process holds one-off host stalls
-    # (first-use initialisation inside the HIP runtime and the caching allocator: a single step of the first
-    # dozen takes 50-80 ms instead of 29), which would otherwise land inside a short timed region.
-    log("model built; settling")
-    t_settle = time.perf_counter() + args.settle
-    n_settle = 0
-    if multi:
-        # every rank must issue the same number of collectives: a fixed count instead of a time budget
-        for _ in range(int(round(args.settle * 30))):
-            one_step()
-            n_settle += 1
-    else:
-        while time.perf_counter() < t_settle:
-            one_step()
-            n_settle += 1
-    torch.cuda.synchronize()
-    log(f"{n_settle} settling steps; warm-up")
-    for _ in range(args.warmup):
-        one_step()
-    log("timed steps")
-    if not multi:
-        model._engine.prof = []
-        model._engine.prof_stride = max(1, args.profile_stride)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step()
-        log(f"rank {rank}: step {i} issued", True)
-    barrier()
-    dt = time.perf_counter() - t0
-    log(f"done: {dt / args.steps * 1e3:.2f} ms/step on this rank")
-    if not multi:
-        prof = model._engine.prof
-        model._engine.prof = None
-    if args.workload.startswith("sample"):
-        assert torch.isfinite(state["x"]).all()
-    else:
-        assert state["loss"] == state["loss"], "loss is NaN"
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        parallel.all_reduce_(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
-    sec_per_step = dt / args.steps
-    total_b = B * world
-    value = total_b / (T_FULL * sec_per_step) if args.workload.startswith("sample") else total_b / sec_per_step
+    results = []
+    for j in jobs:
+        log(f"{j.workload}: settling")
+        n = j.settle()
+        log(f"{j.workload}: {n} settling steps; warm-up and timed steps")
+        dt = j.timed(barrier)
+        log(f"{j.workload}: {dt / args.steps * 1e3:.2f} ms/step on this rank")
+        if ctx["dist"] is not None:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            parallel.all_reduce_(tt, op=ctx["dist"].ReduceOp.MAX)
+            dt = tt.item()
+        res = j.report(dt)
+        if rank == 0 and not multi:
+            if j.sampling:
+                res["hbm_kernel"] = reverse_step_bandwidth(dev, j.B * j.wl["cin"] * j.wl["hw"] * j.wl["hw"])
+                res["full_call"] = j.full_call()
+                res["full_call"]["timed_step_ms"] = res["ms_per_step"]
+        results.append((j, res))
+        if len(jobs) > 1:          # free the first workload's model and activations before the next one runs
+            j.model, j.dm, j.one_step, j.state = None, None, None, {}
+            torch.cuda.empty_cache()
 
-    # per-kernel figures from the HIP events recorded around every MFMA launch of the timed steps
-    agg = {}
-    for label, flops, e0, e1 in prof:
-        a = agg.setdefault(label, [0.0, 0.0, 0])
-        a[0] += flops
-        a[1] += e0.elapsed_time(e1) * 1e-3
-        a[2] += 1
-    if os.environ.get("DDPM_BENCH_PER_SHAPE") and rank == 0:   # diagnostic: the same figures per distinct launch shape
-        shapes = {}
-        for label, flops, e0, e1 in prof:
-            a = shapes.setdefault((label, flops), [0.0, 0])
-            a[0] += e0.elapsed_time(e1) * 1e-3
-            a[1] += 1
-        for (label, flops), (t, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
-            log(f"  {label:40s} {flops / 1e9:9.2f} GFLOP  x{n:3d}  {t / n * 1e6:8.1f} us  {flops * n / t / 1e12:6.1f} TFLOP/s")
-    if not agg:
-        sys.exit(f"no MFMA launch was sampled: lower --profile-stride ({sec_per_step * 1e3:.3f} ms/step)")
-    dom = max(agg.items(), key=lambda kv: kv[1][1])
-    achieved = dom[1][0] / dom[1][1] / 1e12
-    # launches are sampled 1 in `stride` (all of them in the multi-GPU pre-pass): scale the summed time back up
-    prof_steps = args.steps / max(1, args.profile_stride) if not multi else 2
-    kernels = {k: dict(sampled_launches=v[2], avg_ms=round(v[1] / v[2] * 1e3, 4), tflops=round(v[0] / v[1] / 1e12, 2),
-                       peak_tflops=round(kernel_peak(k), 1), frac=round(v[0] / v[1] / 1e12 / kernel_peak(k), 4),
-                       share_of_step=round(v[1] / prof_steps / sec_per_step, 3)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
-    cfg = {"workload": wl["name"], "per_gpu_batch": B, "global_batch": total_b}
-    if args.workload.startswith("sample"):
-        cfg.update(T=T_FULL, step="one denoising step (UNet eval forward + noise draw + fused reverse-step kernel); "
-                                  "images/s = global_batch / (T * seconds_per_step)")
-    else:
-        cfg.update(optimizer=("torch.optim.Adam(lr=2e-4)" if args.optimizer == "torch" else "Adam(lr=2e-4), torch.optim.Adam's update as one HIP launch per 64 tensors"), batchnorm="per-rank batch statistics",
-                   parallelism=("dp%d: %s all-reduce of flattened gradients" % (world, "RCCL" if args.backend == "nccl" else args.backend))
-                   if multi else "single GPU",
-                   last_loss=round(state["loss"], 5))
-    # memory-side bytes per launch of the dominant kernel: not measurable live (hardware counters need their own
-    # rocprofv3 --pmc passes), so taken from the committed summary of tools/pmc_traffic.sh for this workload
-    traffic, traffic_src = None, None
-    kernel_symbol = {"conv3x3_halo<split-bf16>": "conv3x3_halo_kernel", "attention_fwd<split-bf16>": "attention_fwd_x3_kernel"}.get(dom[0])
-    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.txt" % ("sample" if args.workload == "sample" else "train"))
-    if kernel_symbol and args.workload in ("train", "sample") and os.path.exists(tfile):
-        for line in open(tfile):
-            f = line.split()
-            if len(f) > 4 and kernel_symbol in line and f[0].isdigit():
-                traffic = int(float(f[3]) * 1e6)
-                traffic_src = ("bytes per launch, mean over this kernel's launches of one step: rocprofv3 --pmc FETCH_SIZE (x 2, the gfx950 "
-                               "correction for wide loads) + WRITE_SIZE in separate passes, profiles/" + os.path.basename(tfile))
-                break
-    out = {
-        "metric": wl["metric"], "value": round(value, 4), "unit": wl["unit"],
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": cfg,
-        "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(kernel_peak(dom[0]), 1),
-                     "unit": "TFLOP/s", "frac": round(achieved / kernel_peak(dom[0]), 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "sustained_peak": (round(SUSTAINED_BF16_TFLOPS / SPLIT_PRODUCTS, 1) if "split-bf16" in dom[0] else None),
-                     "sustained_peak_note": "a loop of nothing but independent v_mfma_f32_32x32x16_bf16 (tools/probe/mfma_power.hip) "
-                                            "sustains 1.9 PFLOP/s on this chip (1.8 GHz under that load, not the 2.4 GHz of the nominal peak)",
-                     "arithmetic": ("fp32 operands split exactly into 3 bf16 terms, 6 cross products per fp32 product on "
-                                    "v_mfma_f32_32x32x16_bf16 with fp32 accumulation: achieved/peak count algorithmic fp32 FLOP, "
-                                    "peak = bf16 dense peak / 6" if "split-bf16" in dom[0] else "v_mfma_f32_32x32x2_f32"),
-                     "avg_launch_ms": round(dom[1][1] / dom[1][2] * 1e3, 4), "sampled_launches": dom[1][2],
-                     "measured": f"HIP events around every {max(1, args.profile_stride)}-th MFMA launch of the timed steps (rotating over the launch sites)" if not multi else
-                                 "HIP events in a 2-step pre-pass before the process group is created"},
-        "kernels": kernels,
-    }
     if rank == 0:
-        if not multi:
-            out["hbm_kernel"] = reverse_step_bandwidth(dev, B * wl["cin"] * wl["hw"] * wl["hw"])
+        out = results[0][1]
         if not multi and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, wl)
+            for j, res in results:
+                log(f"{j.workload}: CPU baseline")
+                res["cpu_baseline"] = cpu_baseline(j.workload, j.wl, j.B)
+        if len(results) > 1:
+            samp = results[1][1]
+            out["sampling"] = {k: samp[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "kernels", "hbm_kernel",
+                                                    "full_call", "cpu_baseline") if k in samp}
+            out.setdefault("hbm_kernel", samp.get("hbm_kernel"))
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if ctx["dist"] is not None:
+        ctx["dist"].destroy_process_group()
 
 
 if __name__ == "__main__":

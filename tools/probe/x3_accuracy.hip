@@ -1,6 +1,9 @@
 // Accuracy probe: C = A * B^T (A: MxK, B: NxK, fp32) computed three ways and compared with fp64:
 //  (1) v_mfma_f32_32x32x2_f32, (2) three-way bf16 split, 6 cross products on v_mfma_f32_32x32x16_bf16,
-//  (3) the same with only 3 products (hi*hi, hi*mid, mid*hi) for scale.
+//  (3) the same with only 3 products (hi*hi, hi*mid, mid*hi) for scale,
+//  (4), (5) scheme (2) as the library's kernels run it: the MFMA partial sum is folded into a master accumulator with a
+//  round-to-nearest fp32 add every 64 (generic GEMM kernel) or 144 (halo 3x3 kernel: nine taps of a 16-channel chunk)
+//  elements of K, because the bf16 MFMA truncates when it accumulates.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -27,8 +30,9 @@ template <int VARIANT>
 __global__ void gemm_kernel(const float* A, const float* B, float* C, int M, int N, int K) {
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-    f32x16 acc;
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x16 acc, master;
+    for (int e = 0; e < 16; ++e) acc[e] = master[e] = 0.f;
+    const int fold = VARIANT == 3 ? 64 : 144;
     if (VARIANT == 0) {
         for (int k = 0; k < K; k += 2) {
             const float a = A[(m0 + r) * (size_t)K + k + h], b = B[(n0 + r) * (size_t)K + k + h];
@@ -47,12 +51,17 @@ __global__ void gemm_kernel(const float* A, const float* B, float* C, int M, int
             auto mm = [&](s16x8 a, s16x8 b) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
             };
-            if (VARIANT == 1) {  // small terms first
-                mm(al, bh); mm(ah, bl); mm(am, bm); mm(am, bh); mm(ah, bm); mm(ah, bh);
-            } else {
+            if (VARIANT == 2) {
                 mm(am, bh); mm(ah, bm); mm(ah, bh);
+            } else {  // small terms first
+                mm(al, bh); mm(ah, bl); mm(am, bm); mm(am, bh); mm(ah, bm); mm(ah, bh);
+            }
+            if (VARIANT >= 3 && (k + 16) % fold == 0) {
+                for (int e = 0; e < 16; ++e) { master[e] += acc[e]; acc[e] = 0.f; }
             }
         }
+        if (VARIANT >= 3)
+            for (int e = 0; e < 16; ++e) acc[e] += master[e];
     }
     for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -62,7 +71,7 @@ __global__ void gemm_kernel(const float* A, const float* B, float* C, int M, int
 
 int main(int argc, char** argv) {
     const int M = 256, N = 256;
-    for (int K : {64, 576, 2304, 9216}) {
+    for (int K : {576, 2304, 4608, 9216}) {
         for (int dist = 0; dist < 2; ++dist) {
             std::vector<float> A((size_t)M * K), B((size_t)N * K);
             srand(1);
@@ -81,11 +90,13 @@ int main(int argc, char** argv) {
             hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
             hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
             std::vector<float> C((size_t)M * N);
-            for (int v = 0; v < 3; ++v) {
+            for (int v = 0; v < 5; ++v) {
                 dim3 g(M / 32, N / 32);
                 if (v == 0) gemm_kernel<0><<<g, 64>>>(dA, dB, dC, M, N, K);
                 if (v == 1) gemm_kernel<1><<<g, 64>>>(dA, dB, dC, M, N, K);
                 if (v == 2) gemm_kernel<2><<<g, 64>>>(dA, dB, dC, M, N, K);
+                if (v == 3) gemm_kernel<3><<<g, 64>>>(dA, dB, dC, M, N, K);
+                if (v == 4) gemm_kernel<4><<<g, 64>>>(dA, dB, dC, M, N, K);
                 hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost);
                 double maxerr = 0, rms = 0, scale = 0, bias = 0;
                 for (size_t i = 0; i < C.size(); ++i) {
