@@ -309,9 +309,24 @@ class Job:
             stages = dm.sample(self.shape, dev, **kw)
         dt = time.perf_counter() - t0
         assert len(stages) == 10 and stages[-1][1] == 0 and torch.isfinite(stages[-1][0]).all()
-        return dict(T=T, seconds=round(dt, 4), ms_per_step=round(dt / T * 1e3, 3), stages=len(stages),
-                    what="DiffusionModel.sample(x_shape, device, labels) of a T=50 linear schedule at this batch, wall clock "
-                         "including the ten stage copies to pinned host memory")
+        res = dict(T=T, seconds=round(dt, 4), ms_per_step=round(dt / T * 1e3, 3), stages=len(stages),
+                   what="DiffusionModel.sample(x_shape, device, labels) of a T=50 linear schedule at this batch, wall clock "
+                        "including the ten stage copies to pinned host memory")
+        if self.wl["cin"] == 1 and self.wl["hw"] == 32:
+            # the "+classifier.py path" of this configuration: score the samples with the MNIST classifier (random weights
+            # here: the trained ones are not part of the synthetic workload) and reduce to the Inception-Score terms
+            from diffusion_model_amd import scorer
+            torch.manual_seed(1)
+            clf = pkg.SimpleCNN().to(dev).eval()
+            imgs = stages[-1][0]
+            scorer.inception_score(imgs, clf)              # first call packs the weights
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mean, _ = scorer.inception_score(imgs, clf)
+            res["score"] = dict(seconds=round(time.perf_counter() - t0, 5), images=int(imgs.shape[0]), inception_score=round(float(mean), 4),
+                                what="SimpleCNN logits + softmax + 10-split Inception-Score reduction of the final samples (host "
+                                     "images in, scalar out), HIP kernels")
+        return res
 
     # ---- report -------------------------------------------------------------------------------
     def report(self, dt):

@@ -76,6 +76,9 @@ _SIGNATURES = {
     "ddpm_time_embed_bwd": [C.POINTER(EmbedBwdArgs), P],
     "ddpm_attention_bwd": [P, P, I32, P, P, P, P, P, P, P, I32, I32, I32, I32, P],
     "ddpm_attention_fwd": [P, P, I32, P, P, I32, P, P, P, I32, I32, I32, I32, P],
+    "ddpm_softmax_rows": [P, I64, I32, P, P],
+    "ddpm_inception_split_scores": [P, I64, I32, I32, P, P],
+    "ddpm_mean_cov": [P, I64, I32, P, P, P, P],
     "ddpm_adam_step": [I32, P, P, P, P, P, F64, F64, F64, F64, F64, I64, P],
 }
 
@@ -99,6 +102,8 @@ def lib():
         handle.ddpm_reduce_workspace_doubles.argtypes = [I32]
         handle.ddpm_packed_weight_floats.restype = C.c_int64
         handle.ddpm_packed_weight_floats.argtypes = [I32, I32, I32]
+        handle.ddpm_mean_cov_workspace_doubles.restype = C.c_int64
+        handle.ddpm_mean_cov_workspace_doubles.argtypes = [I32]
         for name, sig in _SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the header and library disagree
             fn.argtypes = sig
@@ -108,7 +113,7 @@ def lib():
 
 
 def exported_symbols():
-    return ["ddpm_last_error", "ddpm_reduce_workspace_doubles", "ddpm_packed_weight_floats"] + list(_SIGNATURES)
+    return ["ddpm_last_error", "ddpm_reduce_workspace_doubles", "ddpm_packed_weight_floats", "ddpm_mean_cov_workspace_doubles"] + list(_SIGNATURES)
 
 
 def packed_floats(taps, rows, cin):

@@ -22,6 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ITERATIONS = {"1": "first-iteration", "2": "second-iteration", "3": "third-iteration", "first": "first-iteration",
               "second": "second-iteration", "third": "third-iteration"}
 MODULES = ("beta_scheduler", "embeddings", "diffusion", "unet")
+OPTIONAL = ("classifier",)      # third-iteration only: the scorer's SimpleCNN (third-iteration/metrics2.py:8)
 
 
 def drop_in_dir(iteration):
@@ -40,7 +41,7 @@ def install(iteration, script_dir=None):
         sys.path.insert(0, script_dir)
     sys.path.insert(0, d)
     loaded = {}
-    for name in MODULES:
+    for name in MODULES + tuple(m for m in OPTIONAL if os.path.exists(os.path.join(d, m + ".py"))):
         stale = sys.modules.get(name)
         if stale is not None and os.path.dirname(os.path.abspath(getattr(stale, "__file__", "") or "")) != d:
             del sys.modules[name]                       # an earlier import of the reference's own module

@@ -369,6 +369,32 @@ int ddpm_attention_bwd(const float* qkv, const float* dy, int ldd, const float* 
                        const float* gamma, double* workspace, float* e_scratch, float* dqkv, float* dgamma,
                        int batch, int n, int c, int dq, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Scoring of generated images with the small MNIST classifier (the "+classifier.py path" of the
+ * sampling benchmark). The classifier itself -- conv3x3(1->32)+ReLU+pool, conv3x3(32->64)+ReLU+pool,
+ * fc 4096->128 + ReLU, fc 128->10 (third-iteration/classifier.py:9-24) -- runs on
+ * ddpm_conv3x3_first_fwd, ddpm_pool_skip_fwd, ddpm_conv3x3_fwd and ddpm_conv1x1_fwd (a Linear is a
+ * 1x1 convolution over a one-pixel image); the entry points below are the reductions over its
+ * [n][k] logits that the metric scripts perform (k <= 16 classes).
+ * ------------------------------------------------------------------------------------- */
+
+/* probs = softmax(logits, dim=1), fp32. Replaces F.softmax(classifier(batch), dim=1),
+ * third-iteration/metrics2.py:77. */
+int ddpm_softmax_rows(const float* logits, int64_t n, int k, float* probs, void* stream);
+
+/* Inception-Score terms: for split s of n // splits consecutive rows, py = mean of the rows,
+ * scores[s] = exp(mean_i sum_j p_ij * (log p_ij - log py_j)); rows beyond splits * (n // splits) are
+ * ignored as in the reference. Replaces the loop of third-iteration/metrics2.py:83-87; the mean and
+ * standard deviation over the splits (:89) are the caller's. */
+int ddpm_inception_split_scores(const float* probs, int64_t n, int k, int splits, float* scores, void* stream);
+
+/* mean[k] and unbiased covariance cov[k][k] (float64, as numpy.cov) of the rows of x [n][k]: the
+ * statistics the Frechet distance is computed from. Replaces np.mean(act, axis=0), np.cov(act,
+ * rowvar=False), third-iteration/metrics2.py:107-108 (the 10x10 matrix square root of :112 stays on
+ * the host). workspace: ddpm_mean_cov_workspace_doubles(k) doubles. */
+int64_t ddpm_mean_cov_workspace_doubles(int k);
+int ddpm_mean_cov(const float* x, int64_t n, int k, double* workspace, double* mean, double* cov, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -271,3 +271,46 @@ def adam_step(params, grads, state, lr=2e-4, b1=0.9, b2=0.999, eps=1e-8):
         bc1, bc2 = 1 - b1 ** s, 1 - b2 ** s
         denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
         p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+# ---- scorer: the MNIST classifier and the metrics computed from its logits -------------------------
+def simple_cnn_forward(sd, x):
+    """SimpleCNN.forward, third-iteration/classifier.py:18-24: logits [B, 10] of [B, 1, 32, 32] images."""
+    x = F.max_pool2d(F.relu(F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"], padding=1)), 2, 2)
+    x = F.max_pool2d(F.relu(F.conv2d(x, sd["conv2.weight"], sd["conv2.bias"], padding=1)), 2, 2)
+    x = x.view(x.size(0), -1)
+    x = F.relu(F.linear(x, sd["fc1.weight"], sd["fc1.bias"]))
+    return F.linear(x, sd["fc2.weight"], sd["fc2.bias"])
+
+
+def inception_split_scores(logits, splits=10):
+    """Per-split exp(mean KL) terms of the Inception Score, third-iteration/metrics2.py:77,83-87 -> fp32 [splits]."""
+    preds = F.softmax(logits, dim=1)
+    n = preds.size(0)
+    out = []
+    for k in range(splits):
+        part = preds[k * (n // splits):(k + 1) * (n // splits), :]
+        py = torch.mean(part, dim=0)
+        kl_div = part * (torch.log(part) - torch.log(py.unsqueeze(0)))
+        out.append(torch.exp(torch.mean(torch.sum(kl_div, dim=1))))
+    return torch.stack(out)
+
+
+def inception_score(logits, splits=10):
+    """(mean, std) over the splits, third-iteration/metrics2.py:89."""
+    s = inception_split_scores(logits, splits)
+    return torch.mean(s), torch.std(s)
+
+
+def fid(act_real, act_gen):
+    """Frechet distance between two sets of feature rows (numpy), third-iteration/metrics2.py:107-117."""
+    from scipy.linalg import sqrtm
+    mu_real, sigma_real = np.mean(act_real, axis=0), np.cov(act_real, rowvar=False)
+    mu_gen, sigma_gen = np.mean(act_gen, axis=0), np.cov(act_gen, rowvar=False)
+    diff = mu_real - mu_gen
+    covmean = sqrtm(sigma_real @ sigma_gen)
+    if isinstance(covmean, tuple):
+        covmean = covmean[0]
+    if np.iscomplexobj(covmean):
+        covmean = covmean.real
+    return float(np.sum(diff ** 2) + np.trace(sigma_real + sigma_gen - 2 * covmean))

@@ -299,10 +299,54 @@ def gen_training(mods, variant=2):
     save(f"training_v{variant}.npz", **out)
 
 
+def gen_classifier():
+    """The scorer: SimpleCNN (third-iteration/classifier.py) with the weights the reference ships
+    (mnist_classifier.pth, loaded weights-only), logits of seeded 1x32x32 images, and the Inception Score / Frechet
+    distance the reference's helper functions (third-iteration/utils.py:194-236, the importable twins of the
+    functions inside the metrics2.py script) compute from them. The weights are stored as data: the GPU box has
+    no reference checkout."""
+    for m in ("classifier", "utils"):
+        sys.modules.pop(m, None)
+    d = os.path.join(REF, ITER_DIRS[3])
+    sys.path.insert(0, d)
+    try:
+        classifier = importlib.import_module("classifier")
+        utils = importlib.import_module("utils")
+    finally:
+        sys.path.remove(d)
+    model = classifier.SimpleCNN()
+    sd = torch.load(os.path.join(REF, "mnist_classifier.pth"), map_location="cpu", weights_only=True)
+    model.load_state_dict(sd)
+    model.eval()
+    out = {f"w::{k}": npf(v) for k, v in sd.items()}
+    # "generated": blurred blobs in [-1, 1] so that the classifier is not saturated; "real": another draw
+    def images(n, seed):
+        base = seeded_tensor((n, 1, 32, 32), seed, "img")
+        sm = torch.nn.functional.avg_pool2d(base, 5, 1, 2) * 3.0
+        return torch.tanh(sm + 0.5 * seeded_tensor((n, 1, 1, 1), seed, "bias"))
+    gen, real = images(320, 500), images(200, 501)
+    with torch.no_grad():
+        lg, lr = model(gen), model(real)
+    out["gen_x"], out["real_x"], out["gen_logits"], out["real_logits"] = npf(gen), npf(real), npf(lg), npf(lr)
+    is_mean, is_std = utils.inception_score(gen, model, num_splits=10)
+    out["is_mean_std"] = np.array([is_mean, is_std], dtype=np.float64)
+    out["fid"] = np.array([float(np.real(utils.calculate_fid(lr.numpy(), lg.numpy())))], dtype=np.float64)
+    for m in ("classifier", "utils"):
+        sys.modules.pop(m, None)
+    save("classifier.npz", **out)
+    return {"weights_sha16": {k: sha16(npf(v)) for k, v in sd.items()}}
+
+
 def main():
     assert os.path.isdir(REF), "reference not mounted"
     _stub_missing()
     torch.set_num_threads(1)          # deterministic reduction order on CPU
+    if "--only-classifier" in sys.argv:      # adds classifier.npz without regenerating the other fixtures
+        meta = json.load(open(os.path.join(HERE, "meta.json")))
+        print("classifier"); meta["classifier"] = gen_classifier()
+        with open(os.path.join(HERE, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1)
+        return
     meta = {"torch": torch.__version__, "numpy": np.__version__}
     m1, m2, m3 = load_iteration(1), load_iteration(2), load_iteration(3)
     print("schedules"); meta["schedules_sha16"] = gen_schedules(m1)
@@ -313,6 +357,7 @@ def main():
         print(f"full unet v{v}"); meta[f"full_v{v}"] = gen_full_width(m, v)
         print(f"sampling v{v}"); gen_sampling(m, v)
     print("training"); gen_training(m2, 2)
+    print("classifier"); meta["classifier"] = gen_classifier()
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1)
 

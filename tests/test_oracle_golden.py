@@ -173,3 +173,19 @@ def test_training_trace(meta):
         O.adam_step(params, grads, state)
         losses.append(loss.item())
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-3)
+
+
+def test_scorer_oracle_matches_reference_logits_and_metrics():
+    """SimpleCNN with the reference's shipped weights, Inception Score and Frechet distance (golden: classifier.npz)."""
+    g = load_golden("classifier.npz")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w::")}
+    assert sorted(sd) == ["conv1.bias", "conv1.weight", "conv2.bias", "conv2.weight", "fc1.bias", "fc1.weight", "fc2.bias", "fc2.weight"]
+    for tag in ("gen", "real"):
+        got = O.simple_cnn_forward(sd, torch.from_numpy(g[f"{tag}_x"]))
+        want = torch.from_numpy(g[f"{tag}_logits"])
+        assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    mean, std = O.inception_score(torch.from_numpy(g["gen_logits"]), 10)
+    assert abs(mean.item() - g["is_mean_std"][0]) <= 1e-5 * g["is_mean_std"][0]
+    assert abs(std.item() - g["is_mean_std"][1]) <= 1e-4 * max(g["is_mean_std"][1], 1e-3)
+    f = O.fid(g["real_logits"], g["gen_logits"])
+    assert abs(f - g["fid"][0]) <= 1e-6 * max(1.0, abs(g["fid"][0]))
