@@ -41,6 +41,10 @@ _SIGNATURES = {
     "ddpm_schedule_tables": [I32, P, P, P],
     "ddpm_step_coefficients": [F32, F32, F32, P],
     "ddpm_reverse_step": [P, P, P, F32, P, F32, F32, F32, P, I64, P],
+    "ddpm_philox_normal": [P, I64, C.c_uint64, C.c_uint64, P],
+    "ddpm_final_conv_reverse_step": [P, I32, P, P, P, P, F32, I32, P, C.c_uint64, C.c_uint64, F32, F32, F32, P, P, I32, I32, I32, I32, I32, P],
+    "ddpm_postprocess_images": [P, P, I64, P],
+    "ddpm_make_grid": [P, I32, I32, I32, I32, I32, I32, F32, I32, F32, F32, P, P],
     "ddpm_add_noise": [P, P, P, P, I32, P, I32, I64, P],
     "ddpm_mse_partial_count": [],
     "ddpm_mse_fwd": [P, P, I64, P, P, P],

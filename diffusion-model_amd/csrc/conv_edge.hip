@@ -2,6 +2,7 @@
 // cores: the first 3x3 conv (1 or 3 input channels, NCHW image in, NHWC out) and the final 1x1
 // conv (NHWC in, 1 or 3 channels, NCHW out). Both are memory-bound.
 #include "common.h"
+#include "process_math.h"
 
 using ddpm::as_stream;
 
@@ -97,7 +98,88 @@ __global__ __launch_bounds__(256) void conv1x1_final_kernel(const float* __restr
     }
 }
 
+// The final 1x1 conv and the reverse ancestral step in one pass: eps-hat never goes to memory. Same thread
+// layout and the same summation order as conv1x1_final_kernel (so eps-hat has the same bits), followed by
+// the reverse-step expression on the lane that holds the pixel's sum. Noise: an injected tensor (NOISE = 1),
+// drawn in place from the Philox stream (NOISE = 2), or none (NOISE = 0: the t == 0 step).
+struct FinalStepArgs {
+    const float* feat;       // [B][hw][ld] NHWC features
+    const float* w;          // [cout][c]
+    const float* bias;       // [cout] or null
+    const float* x_t;        // [B][cout][hw] NCHW
+    const float* z;          // NCHW noise (NOISE == 1)
+    const float* eps_cond;   // NCHW conditional eps-hat: this pass is the unconditional one of a guided step (or null)
+    float* x_out;            // NCHW
+    float* eps_out;          // optional NCHW copy of this pass's eps-hat (or null)
+    float c1, c2, c3, cfg_w;
+    uint64_t seed, call;
+    int ld, batch, hw, c, cout;
+};
+
+template <int NOISE>
+__global__ __launch_bounds__(256) void final_step_kernel(const FinalStepArgs a) {
+    __shared__ __attribute__((aligned(16))) float sw[kMaxLdsFloats];
+    for (int i = threadIdx.x; i < a.c * a.cout; i += blockDim.x) sw[i] = a.w[i];
+    __syncthreads();
+    const int sub = threadIdx.x & 15;
+    const int64_t npix = static_cast<int64_t>(a.batch) * a.hw;
+    const int64_t groups = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 4);
+    const int64_t iters = (npix + groups - 1) / groups;
+    const bool low = fabsf(a.cfg_w) < 0.5f;
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t pix = it * groups + static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 4) + (threadIdx.x >> 4);
+        const bool live = pix < npix;
+        for (int co = 0; co < a.cout; ++co) {
+            float acc = 0.f;
+            if (live) {
+                for (int c0 = sub * 4; c0 < a.c; c0 += 64) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.feat + pix * a.ld + c0);
+                    const float4 wv = *reinterpret_cast<const float4*>(sw + co * a.c + c0);
+                    acc += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+                }
+            }
+            acc += __shfl_xor(acc, 8);
+            acc += __shfl_xor(acc, 4);
+            acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 1);
+            if (live && sub == 0) {
+                const int64_t b = pix / a.hw, q = pix % a.hw;
+                const int64_t e = (b * a.cout + co) * a.hw + q;
+                float eps = acc + (a.bias ? a.bias[co] : 0.f);
+                if (a.eps_out) a.eps_out[e] = eps;
+                if (a.eps_cond) eps = ddpm::guided_eps(a.eps_cond[e], eps, a.cfg_w, low);
+                float zv = 0.f;
+                if (NOISE == 1) zv = a.z[e];
+                if (NOISE == 2) zv = ddpm::philox_normal(a.seed, a.call, static_cast<uint64_t>(e));
+                a.x_out[e] = ddpm::step1(a.x_t[e], eps, zv, a.c1, a.c2, a.c3, NOISE != 0);
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int ddpm_final_conv_reverse_step(const float* feat, int ld, const float* w, const float* bias, const float* x_t,
+                                            const float* eps_cond, float cfg_w, int noise_mode, const float* z, uint64_t seed,
+                                            uint64_t call, float c1, float c2, float c3, float* x_out, float* eps_out, int batch, int h,
+                                            int w_, int c, int cout, void* stream) {
+    DDPM_REQUIRE(feat && w && x_t && x_out && batch > 0 && h > 0 && w_ > 0 && c > 0 && cout > 0);
+    DDPM_REQUIRE((c & 3) == 0 && (ld & 3) == 0 && ld >= c && ddpm::aligned16(feat));
+    DDPM_REQUIRE(c * cout <= kMaxLdsFloats);
+    DDPM_REQUIRE(noise_mode >= 0 && noise_mode <= 2 && (noise_mode != 1 || z));
+    FinalStepArgs a;
+    a.feat = feat; a.w = w; a.bias = bias; a.x_t = x_t; a.z = z; a.eps_cond = eps_cond; a.x_out = x_out; a.eps_out = eps_out;
+    a.c1 = c1; a.c2 = c2; a.c3 = c3; a.cfg_w = cfg_w; a.seed = seed; a.call = call;
+    a.ld = ld; a.batch = batch; a.hw = h * w_; a.c = c; a.cout = cout;
+    const int64_t npix = static_cast<int64_t>(batch) * h * w_;
+    int64_t grid = (npix + 15) / 16;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipStream_t s = as_stream(stream);
+    if (noise_mode == 0) final_step_kernel<0><<<static_cast<int>(grid), 256, 0, s>>>(a);
+    else if (noise_mode == 1) final_step_kernel<1><<<static_cast<int>(grid), 256, 0, s>>>(a);
+    else final_step_kernel<2><<<static_cast<int>(grid), 256, 0, s>>>(a);
+    return ddpm::check_launch("final_step_kernel");
+}
 
 extern "C" int ddpm_conv3x3_first_fwd(const float* x_nchw, const float* w, const ddpm_epilogue* ep, int act, float* out, int batch,
                                       int cin, int h, int w_, int cout, int ldo, void* stream) {

@@ -1,6 +1,7 @@
 // HBM-bound elementwise kernels of the diffusion process: reverse ancestral step, forward noising,
 // eps-MSE loss, max-pool + skip hand-off, time-embedding broadcast add.
 #include "common.h"
+#include "process_math.h"
 
 // The process kernels promise separately rounded fp32 operations: never contract a*b+c into an FMA.
 #pragma clang fp contract(off)
@@ -19,20 +20,14 @@ __host__ inline int grid_for(int64_t work_items, int per_block, int cap = 256 * 
 }
 
 // ---- reverse step ---------------------------------------------------------------------------
-// The reference evaluates c1*(x - c2*eps) + c3*z as five separately rounded fp32 operations;
-// the explicit _rn intrinsics keep the compiler from contracting them into FMAs.
-__device__ __forceinline__ float guided_eps(float e_c, float e_u, float w, bool low) {
-    // torch.lerp(start=e_u, end=e_c, weight=w)
-    const float d = __fsub_rn(e_c, e_u);
-    return low ? __fadd_rn(e_u, __fmul_rn(w, d)) : __fsub_rn(e_c, __fmul_rn(d, __fsub_rn(1.0f, w)));
-}
+using ddpm::guided_eps;
+using ddpm::step1;
 
-__device__ __forceinline__ float step1(float x, float e, float z, float c1, float c2, float c3, bool has_z) {
-    const float inner = __fsub_rn(x, __fmul_rn(c2, e));
-    const float a = __fmul_rn(c1, inner);
-    // t == 0: the reference still adds sqrt(beta)*0 = +0, which leaves `a` unchanged except that
-    // -0 + +0 = +0; adding 0.0f reproduces exactly that.
-    return has_z ? __fadd_rn(a, __fmul_rn(c3, z)) : __fadd_rn(a, 0.0f);
+// z[i] = element i of the Gaussian stream (seed, call): what the fused final-conv + step kernel draws in place.
+__global__ __launch_bounds__(kThreads) void philox_normal_kernel(float* __restrict__ z, int64_t n, uint64_t seed, uint64_t call) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+        z[i] = ddpm::philox_normal(seed, call, static_cast<uint64_t>(i));
 }
 
 template <bool HAS_Z, bool HAS_U>
@@ -70,6 +65,45 @@ __global__ __launch_bounds__(kThreads) void reverse_step_kernel(const float* __r
         float e = eps[i];
         if (HAS_U) e = guided_eps(e, eps_u[i], w, low);
         out[i] = step1(x[i], e, HAS_Z ? z[i] : 0.f, c1, c2, c3, HAS_Z);
+    }
+}
+
+// ---- hand-off to the callers: [-1, 1] samples -> [0, 1] images, and the image grid ---------------------
+// img = clamp((x + 1) / 2, 0, 1) with torch's roundings (one add, an exact halving) and its NaN propagation.
+__device__ __forceinline__ float to_unit_range(float x) {
+    const float v = __fmul_rn(__fadd_rn(x, 1.0f), 0.5f);
+    return v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+}
+
+__global__ __launch_bounds__(kThreads) void postprocess_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = to_unit_range(x[i]);
+}
+
+// One thread per grid element: image k = row*xmaps + col occupies rows [row*(h+pad)+pad, +h) and the matching
+// columns; everything else (and cells beyond the last image) is pad_value. Single-channel images are repeated
+// over the three grid channels. normalize: v = (clamp(v, lo, hi) - lo) / max(hi - lo, 1e-5).
+__global__ __launch_bounds__(kThreads) void make_grid_kernel(const float* __restrict__ img, int n, int c, int h, int w, int xmaps,
+                                                              int pad, float pad_value, int normalize, float lo, float hi, int gc, int gh,
+                                                              int gw, float* __restrict__ grid) {
+    const int64_t total = static_cast<int64_t>(gc) * gh * gw;
+    const float span = fmaxf(__fsub_rn(hi, lo), 1e-5f);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int gx = static_cast<int>(i % gw), gy = static_cast<int>((i / gw) % gh), ch = static_cast<int>(i / (static_cast<int64_t>(gw) * gh));
+        const int cy = gy / (h + pad), cx = gx / (w + pad);
+        const int iy = gy % (h + pad) - pad, ix = gx % (w + pad) - pad;
+        const int64_t k = static_cast<int64_t>(cy) * xmaps + cx;
+        float v = pad_value;
+        // the trailing `pad` rows / columns of the grid fall into cell row ymaps / cell column xmaps with iy, ix < 0
+        if (iy >= 0 && ix >= 0 && cx < xmaps && k < n) {
+            v = img[((k * c + (c == 1 ? 0 : ch)) * h + iy) * w + ix];
+            if (normalize) {
+                v = v < lo ? lo : (v > hi ? hi : v);
+                v = __fdiv_rn(__fsub_rn(v, lo), span);
+            }
+        }
+        grid[i] = v;
     }
 }
 
@@ -243,6 +277,31 @@ extern "C" int ddpm_reverse_step(const float* x, const float* eps, const float* 
     else
         reverse_step_kernel<false, false><<<grid, kThreads, 0, s>>>(x, eps, nullptr, cfg_w, nullptr, c1, c2, c3, x_out, n);
     return ddpm::check_launch("reverse_step_kernel");
+}
+
+extern "C" int ddpm_philox_normal(float* z, int64_t n, uint64_t seed, uint64_t call, void* stream) {
+    DDPM_REQUIRE(z && n >= 0);
+    if (n == 0) return DDPM_OK;
+    philox_normal_kernel<<<grid_for(n, kThreads, 256 * 32), kThreads, 0, as_stream(stream)>>>(z, n, seed, call);
+    return ddpm::check_launch("philox_normal_kernel");
+}
+
+extern "C" int ddpm_postprocess_images(const float* x, float* out, int64_t n, void* stream) {
+    DDPM_REQUIRE(x && out && n >= 0);
+    if (n == 0) return DDPM_OK;
+    postprocess_kernel<<<grid_for(n, kThreads, 256 * 32), kThreads, 0, as_stream(stream)>>>(x, out, n);
+    return ddpm::check_launch("postprocess_kernel");
+}
+
+extern "C" int ddpm_make_grid(const float* images, int n, int c, int h, int w, int nrow, int padding, float pad_value, int normalize,
+                              float lo, float hi, float* grid, void* stream) {
+    DDPM_REQUIRE(images && grid && n > 0 && c > 0 && h > 0 && w > 0 && nrow > 0 && padding >= 0);
+    const int xmaps = nrow < n ? nrow : n, ymaps = (n + xmaps - 1) / xmaps;
+    const int gc = c == 1 ? 3 : c, gh = (h + padding) * ymaps + padding, gw = (w + padding) * xmaps + padding;
+    const int64_t total = static_cast<int64_t>(gc) * gh * gw;
+    make_grid_kernel<<<grid_for(total, kThreads, 256 * 32), kThreads, 0, as_stream(stream)>>>(images, n, c, h, w, xmaps, padding, pad_value,
+                                                                                            normalize, lo, hi, gc, gh, gw, grid);
+    return ddpm::check_launch("make_grid_kernel");
 }
 
 extern "C" int ddpm_add_noise(const float* x0, const float* noise, const int64_t* t, const float* alpha_bar, int timesteps,

@@ -144,6 +144,18 @@ class UNetEngine(TrainMixin):
             return out, fms
         return self.forward_eval(x, t, y)
 
+    def denoise_step(self, x, t, y, step):
+        """x_{t-1} from x_t: eval-mode UNet forward whose final 1x1 conv is fused with the reverse step (no gradients)."""
+        if x.dtype != torch.float32:
+            x = x.float()
+        t = t.to(x.device)
+        if y is not None:
+            if self.num_classes is None:
+                raise AttributeError("this UNet was built without num_classes; it has no label embedding")
+            y = y.to(device=x.device, dtype=torch.int64).contiguous()
+        with torch.no_grad():
+            return self.forward_eval(x, t, y, step=step)
+
     # ------------------------------------------------------------------ parameters and caches
     def T(self, key):
         if self._tensors is None:
@@ -356,7 +368,9 @@ class UNetEngine(TrainMixin):
                      _ptr(self.T(key + ".gamma")), out.ptr, out.ld, _ptr(raw), _ptr(lse), _ptr(temb), b, n, c, dqp, _stream())
 
     # ------------------------------------------------------------------ whole network, eval mode
-    def forward_eval(self, x, t, y=None, want_fms=True):
+    def forward_eval(self, x, t, y=None, want_fms=True, step=None):
+        """Eval-mode forward. With `step` (a dict: c1, c2, c3, noise_mode, z, seed, call, eps_cond, cfg_w, out) the last
+        layer and the reverse ancestral step run as one kernel and the return value is x_{t-1} instead of eps-hat."""
         B, cin, H, W = x.shape
         if cin != self.cin:
             raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
@@ -418,8 +432,20 @@ class UNetEngine(TrainMixin):
             self.convT(hcur, key + ".up", View(cat, cskip, cskip))
             hcur = tail(View(cat), key + ".conv", key + ".attention", cout, te, h, w)
 
-        out = torch.empty((B, self.cout_final, H, W), device=dev, dtype=torch.float32)
         fw = self.T("final_conv.weight")
+        if step is not None:
+            if self.cout_final != cin:
+                raise RuntimeError("the fused reverse step needs out_channels == in_channels (eps-hat has the shape of x_t)")
+            out = step.get("out")
+            if out is None:
+                out = torch.empty_like(x)
+            z, ec = step.get("z"), step.get("eps_cond")
+            call("ddpm_final_conv_reverse_step", hcur.ptr, hcur.ld, _ptr(fw), _ptr(self.T("final_conv.bias")), _ptr(x), _ptr(ec),
+                 float(step.get("cfg_w", 0.0)), int(step["noise_mode"]), _ptr(z), C.c_uint64(step.get("seed", 0)),
+                 C.c_uint64(step.get("call", 0)), step["c1"], step["c2"], step["c3"], _ptr(out), _ptr(step.get("eps_out")), B, H, W, bc,
+                 self.cout_final, _stream())
+            return out, ([f.nchw() for f in fms] if want_fms else [])
+        out = torch.empty((B, self.cout_final, H, W), device=dev, dtype=torch.float32)
         call("ddpm_conv1x1_final_fwd", hcur.ptr, hcur.ld, _ptr(fw), _ptr(self.T("final_conv.bias")), _ptr(out), B, H, W, bc,
              self.cout_final, _stream())
         return out, ([f.nchw() for f in fms] if want_fms else [])

@@ -70,8 +70,17 @@ class _DiffusionBase:
             return self.model(x_t, t_tensor, labels)
         return self.model(x_t, t_tensor)
 
-    def _sample(self, x_shape, device, labels, cfg_scale, noise):
-        """noise: optional (x_T, [z_{T-1}, ..., z_1]) to inject instead of drawing (parity tests)."""
+    def _fusable(self):
+        """The model is this package's UNet in eval mode: its last layer can be fused with the reverse step."""
+        m = self.model
+        return hasattr(m, "denoise_step") and hasattr(m, "_engine") and not m.training and self.fuse_final_step
+
+    fuse_final_step = True     # class-level switch (tests compare the fused and the two-kernel paths)
+
+    def _sample(self, x_shape, device, labels, cfg_scale, noise, in_kernel_noise=False):
+        """noise: optional (x_T, [z_{T-1}, ..., z_1]) to inject instead of drawing (parity tests).
+        in_kernel_noise: draw the per-step noise inside the fused step kernel from a Philox stream (seeded from
+        torch's CPU generator, one stream per step) instead of torch.randn_like: no z tensor, no separate launch."""
         x_shape = tuple(x_shape)
         if noise is not None:
             x_t = torch.as_tensor(noise[0], dtype=torch.float32).to(device).contiguous()
@@ -84,24 +93,40 @@ class _DiffusionBase:
             labels = labels.to(x_t.device)
         stages, zi = [], 0
         T = self.num_timesteps
+        fused = self._fusable() and x_t.dim() == 4
+        philox = bool(in_kernel_noise) and zs is None
+        if philox and not fused:
+            raise RuntimeError("in_kernel_noise needs this package's UNet in eval mode (the noise is drawn by its fused last kernel)")
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if philox else 0
         for t in reversed(range(T)):
             t_tensor = torch.full((x_shape[0],), t, dtype=torch.long, device=x_t.device)
-            eps = self._model_call(x_t, t_tensor, labels).contiguous()
-            eps_u = None
-            if cfg_scale > 0:
-                eps_u = self.model(x_t, t_tensor, None).contiguous()
             c1, c2, c3 = step_coefficients_host(self._betas_h[t], self._alphas_h[t], self._abar_h[t])
             z = None
-            if t > 0:
+            if t > 0 and not philox:
                 if zs is not None:
                     z = torch.as_tensor(zs[zi], dtype=torch.float32).to(x_t.device).contiguous()
                     zi += 1
                 else:
                     z = torch.randn_like(x_t)                # per-step noise from the device generator
-            x_next = torch.empty_like(x_t)
-            call("ddpm_reverse_step", _p(x_t), _p(eps), _p(eps_u), float(cfg_scale), _p(z), c1, c2, c3, _p(x_next),
-                 x_t.numel(), _stream())
-            x_t = x_next
+            if fused:
+                # the UNet's final 1x1 conv and the update are one kernel: eps-hat is consumed where it is produced
+                step = dict(c1=c1, c2=c2, c3=c3, noise_mode=0 if t == 0 else (2 if philox else 1), z=z, seed=seed, call=t)
+                x_t = x_t.contiguous()
+                if cfg_scale > 0:
+                    step.update(eps_cond=self._model_call(x_t, t_tensor, labels).contiguous(), cfg_w=float(cfg_scale))
+                    x_t = self.model.denoise_step(x_t, t_tensor, None, step)
+                else:
+                    x_t = self.model.denoise_step(x_t, t_tensor, labels if self._passes_labels else None, step)
+            else:
+                eps = self._model_call(x_t, t_tensor, labels).contiguous()
+                eps_u = None
+                if cfg_scale > 0:
+                    eps_u = self.model(x_t, t_tensor, None).contiguous()
+                x_next = torch.empty_like(x_t)
+                # ddpm_reverse_step blends lerp(eps_uncond, eps, w): the conditional prediction is `eps`
+                call("ddpm_reverse_step", _p(x_t), _p(eps), _p(eps_u), float(cfg_scale), _p(z), c1, c2, c3, _p(x_next),
+                     x_t.numel(), _stream())
+                x_t = x_next
             if x_t.shape != x_shape:
                 raise ValueError(f"Unexpected shape after update: {x_t.shape}, expected: {x_shape}")
             if t % (T // 10) == 0 or t == 0:
@@ -111,21 +136,64 @@ class _DiffusionBase:
                 host = torch.empty(x_t.shape, dtype=x_t.dtype, pin_memory=True)
                 host.copy_(x_t, non_blocking=True)
                 stages.append((host, t))
+        self._final_on_device = x_t
         torch.cuda.current_stream(x_t.device).synchronize()
         return stages
+
+    def sample_images(self, x_shape, device='cpu', **kwargs):
+        """One batch of finished images in [0, 1] on the host: sample() followed by the callers' `(x + 1) / 2` and
+        `clamp(0, 1)` (first-iteration/generate_samples.py:34-37), applied on the GPU before the copy to the host."""
+        self.sample(x_shape, device, **kwargs)
+        imgs = to_images(self._final_on_device)
+        self._final_on_device = None
+        return imgs.cpu()
+
+
+def to_images(samples):
+    """clamp((x + 1) / 2, 0, 1): the two lines every caller applies to sample()'s last stage
+    (first-iteration/generate_samples.py:36-37), as one kernel on a GPU tensor (same bits as the torch expression)."""
+    _need_gpu(samples, "to_images")
+    x = samples.contiguous().float()
+    out = torch.empty_like(x)
+    call("ddpm_postprocess_images", _p(x), _p(out), x.numel(), _stream())
+    return out
+
+
+def make_grid(images, nrow=8, padding=2, normalize=False, pad_value=0.0):
+    """torchvision.utils.make_grid for a [N, C, H, W] GPU tensor with its default value_range / scale_each
+    (first-iteration/generate_samples.py:71,93 call it with nrow and normalize=True): one kernel writes the grid."""
+    _need_gpu(images, "make_grid")
+    if images.dim() != 4:
+        raise ValueError("make_grid expects a [N, C, H, W] tensor")
+    x = images.contiguous().float()
+    n, c, h, w = x.shape
+    lo = hi = 0.0
+    if normalize:
+        mn, mx = torch.aminmax(x)
+        lo, hi = float(mn), float(mx)
+    if n == 1:                                             # torchvision returns the (normalised, 3-channel) image itself
+        y = x.expand(1, 3, h, w) if c == 1 else x
+        if normalize:
+            y = (y.clamp(lo, hi) - lo) / max(hi - lo, 1e-5)
+        return y[0].contiguous()
+    xmaps = min(nrow, n)
+    ymaps = -(-n // xmaps)
+    grid = torch.empty((3 if c == 1 else c, (h + padding) * ymaps + padding, (w + padding) * xmaps + padding), device=x.device)
+    call("ddpm_make_grid", _p(x), n, c, h, w, int(nrow), int(padding), float(pad_value), int(bool(normalize)), lo, hi, _p(grid), _stream())
+    return grid
 
 
 def make_diffusion_class(iteration):
     if iteration in (1, 2):
         class DiffusionModel(_DiffusionBase):
-            def sample(self, x_shape, device='cpu', *, noise=None):
+            def sample(self, x_shape, device='cpu', *, noise=None, in_kernel_noise=False):
                 """Probabilistic sampling method (DDPM-style) with x_shape handling batch size."""
-                return self._sample(x_shape, device, None, 0.0, noise)
+                return self._sample(x_shape, device, None, 0.0, noise, in_kernel_noise)
     else:
         class DiffusionModel(_DiffusionBase):
             _passes_labels = True
 
-            def sample(self, x_shape, device='cpu', labels=None, cfg_scale=0.0, *, noise=None):
+            def sample(self, x_shape, device='cpu', labels=None, cfg_scale=0.0, *, noise=None, in_kernel_noise=False):
                 """Probabilistic sampling method (DDPM-style)."""
-                return self._sample(x_shape, device, labels, cfg_scale, noise)
+                return self._sample(x_shape, device, labels, cfg_scale, noise, in_kernel_noise)
     return DiffusionModel

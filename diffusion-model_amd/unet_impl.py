@@ -102,6 +102,17 @@ class _UNetBase(nn.Module):
         return out
 
 
+    def denoise_step(self, x_t, t, y, step):
+        """One reverse ancestral step through this network (eval mode): x_{t-1}; see UNetEngine.forward_eval."""
+        self.feature_maps.clear()
+        if not x_t.is_cuda:
+            raise RuntimeError("this UNet runs on the MI355X only: move the model and its inputs to the GPU "
+                               "(there is no CPU fallback)")
+        out, fms = self._engine.denoise_step(x_t, t, y, step)
+        self.feature_maps.extend(fms)
+        return out
+
+
 def make_unet_class(iteration):
     if iteration == 1:
         class UNet(_UNetBase):

@@ -75,6 +75,45 @@ int ddpm_reverse_step(const float* x, const float* eps, const float* eps_uncond,
                       const float* z, float c1, float c2, float c3, float* x_out, int64_t n,
                       void* stream);
 
+/* z[i] = standard-normal element i of the counter-based stream (seed, call): Philox4x32-10 with
+ * counter (i / 4, call) and key seed, two Box-Muller pairs per block. The same stream that
+ * ddpm_final_conv_reverse_step draws in place with noise_mode 2 (bit for bit). Stands in for the
+ * per-step torch.randn_like(x_t), first-iteration/diffusion.py:31 (the reference never seeds it). */
+int ddpm_philox_normal(float* z, int64_t n, uint64_t seed, uint64_t call, void* stream);
+
+/* The last layer of the UNet and the reverse step as ONE kernel, for the sampling loop: eps-hat =
+ * final 1x1 conv of the NHWC features (c channels, stride ld; w [cout][c], bias [cout]) is formed per
+ * pixel exactly as ddpm_conv1x1_final_fwd forms it (same bits) and consumed on the spot by the
+ * reverse-step expression of ddpm_reverse_step (same five roundings): x_out = c1*(x_t - c2*eps) +
+ * c3*z, all NCHW [batch][cout][h][w]. eps-hat makes no round trip through memory: 12 B per element
+ * beside the feature read (x_t, z, x_out), 8 B with in-kernel noise.
+ *   noise_mode 0: no noise term (the t == 0 step); 1: z is read from `z`; 2: z is drawn in place,
+ *   element i of the stream (seed, call) of ddpm_philox_normal.
+ *   eps_cond != NULL: this pass is the unconditional one of a classifier-free-guidance step and
+ *   eps = lerp(eps_this, eps_cond, cfg_w) first (third-iteration/diffusion.py:29-31).
+ *   eps_out != NULL additionally stores this pass's eps-hat (NCHW).
+ * x_out may alias x_t. Replaces first-iteration/unet.py:115 + first-iteration/diffusion.py:30-37. */
+int ddpm_final_conv_reverse_step(const float* feat, int ld, const float* w, const float* bias,
+                                 const float* x_t, const float* eps_cond, float cfg_w, int noise_mode,
+                                 const float* z, uint64_t seed, uint64_t call, float c1, float c2, float c3,
+                                 float* x_out, float* eps_out, int batch, int h, int w_, int c, int cout,
+                                 void* stream);
+
+/* Hand-off of finished samples to the callers: out = clamp((x + 1) / 2, 0, 1), the two lines every
+ * caller applies to sample()'s last stage (first-iteration/generate_samples.py:36-37,87-88), with
+ * torch's roundings and NaN propagation. out may alias x. */
+int ddpm_postprocess_images(const float* x, float* out, int64_t n, void* stream);
+
+/* The image grid the callers save (make_grid(images, nrow=..., normalize=True),
+ * first-iteration/generate_samples.py:71,93): images [n][c][h][w] -> grid [c == 1 ? 3 : c][gh][gw],
+ * xmaps = min(nrow, n) images per row, ymaps = ceil(n / xmaps) rows, gh = (h + padding) * ymaps +
+ * padding, gw likewise; image k sits at row k / xmaps, column k % xmaps behind `padding` pixels of
+ * pad_value; single-channel images are repeated over three channels; normalize != 0 maps v to
+ * (clamp(v, lo, hi) - lo) / max(hi - lo, 1e-5) (lo, hi = the tensor's min and max, the caller's).
+ * torchvision's n == 1 shortcut (the image itself, no grid) is the caller's. */
+int ddpm_make_grid(const float* images, int n, int c, int h, int w, int nrow, int padding, float pad_value,
+                   int normalize, float lo, float hi, float* grid, void* stream);
+
 /* out[b,:] = sqrt(abar[t[b]])*x0[b,:] + sqrt(1-abar[t[b]])*noise[b,:]; t: device int64 [batch],
  * alpha_bar: device fp32 [timesteps]; per_sample = C*H*W elements.
  * Replaces DiffusionModel.add_noise, first-iteration/diffusion.py:12-15. */

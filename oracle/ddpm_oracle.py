@@ -314,3 +314,37 @@ def fid(act_real, act_gen):
     if np.iscomplexobj(covmean):
         covmean = covmean.real
     return float(np.sum(diff ** 2) + np.trace(sigma_real + sigma_gen - 2 * covmean))
+
+
+# ---- hand-off to the callers -------------------------------------------------------------------------
+def to_images(x):
+    """(x + 1) / 2 then clamp to [0, 1], first-iteration/generate_samples.py:36-37 (torch tensor in, tensor out)."""
+    return torch.clamp((x + 1) / 2, 0, 1)
+
+
+def make_grid(tensor, nrow=8, padding=2, normalize=False, pad_value=0.0):
+    """Restatement of torchvision.utils.make_grid (torchvision 0.2x, un-pinned in requirements.txt:4; not installed
+    in the build image, so this function is pinned by no fixture: parity unpinned) for a 4-D tensor with the default
+    value_range / scale_each, as first-iteration/generate_samples.py:71,93 call it."""
+    if tensor.dim() == 4 and tensor.size(1) == 1:
+        tensor = torch.cat((tensor, tensor, tensor), 1)
+    if normalize:
+        tensor = tensor.clone()
+        low, high = float(tensor.min()), float(tensor.max())
+        tensor.clamp_(min=low, max=high)
+        tensor.sub_(low).div_(max(high - low, 1e-5))
+    if tensor.size(0) == 1:
+        return tensor.squeeze(0)
+    nmaps = tensor.size(0)
+    xmaps = min(nrow, nmaps)
+    ymaps = int(math.ceil(float(nmaps) / xmaps))
+    height, width = int(tensor.size(2) + padding), int(tensor.size(3) + padding)
+    grid = tensor.new_full((tensor.size(1), height * ymaps + padding, width * xmaps + padding), pad_value)
+    k = 0
+    for y in range(ymaps):
+        for x in range(xmaps):
+            if k >= nmaps:
+                break
+            grid.narrow(1, y * height + padding, height - padding).narrow(2, x * width + padding, width - padding).copy_(tensor[k])
+            k = k + 1
+    return grid
