@@ -110,6 +110,29 @@ def reverse_step_bandwidth(dev, loop_elements, big=1 << 26, iters=20):
         gbps = 16.0 * n / (ms * 1e-3) / 1e9
         res[tag] = {"elements": n, "avg_ms": round(ms, 4), "achieved": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)}
         del x, eps, z, out
+    # the kernel the sampling loop actually runs: final 1x1 conv (64 channels -> 1) fused with the update. Per output element it
+    # reads the pixel's 64 features (256 B) + x_t (+ z) and writes x_{t-1}: 268 B with an injected z, 264 B with in-kernel noise;
+    # the step's own share is 12 B (8 B) instead of the standalone kernel's 16 B + the 8 B eps-hat round trip it removes
+    B, hw, c = 4096, 1024, 64
+    feat, w, bias = torch.randn(B * hw, c, device=dev), torch.randn(1, c, device=dev), torch.zeros(1, device=dev)
+    x, z = torch.randn(B * hw, device=dev), torch.randn(B * hw, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for tag, mode, nbytes in (("fused_final_step_injected_z", 1, 4 * c + 12), ("fused_final_step_in_kernel_noise", 2, 4 * c + 8)):
+        fn = lambda: call("ddpm_final_conv_reverse_step", C.c_void_p(feat.data_ptr()), c, C.c_void_p(w.data_ptr()),  # noqa: E731
+                          C.c_void_p(bias.data_ptr()), C.c_void_p(x.data_ptr()), None, 0.0, mode, C.c_void_p(z.data_ptr()), C.c_uint64(1),
+                          C.c_uint64(2), 1.01, 0.02, 0.1, C.c_void_p(x.data_ptr()), None, B, 32, 32, c, 1, st)
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        gbps = nbytes * B * hw / (ms * 1e-3) / 1e9
+        res[tag] = {"elements": B * hw, "bytes_per_element": nbytes, "avg_ms": round(ms, 4), "achieved": round(gbps, 1),
+                    "frac": round(gbps / HBM_PEAK_GBPS, 4)}
     return res
 
 
@@ -195,12 +218,12 @@ class Job:
                 x, t = state["x"], state["t"]
                 with torch.no_grad():
                     tt = torch.full((B,), t, dtype=torch.long, device=dev)
-                    eps = model(x, tt, labels) if wl["variant"] == 3 else model(x, tt)
                     c1, c2, c3 = step_coefficients_host(dm._betas_h[t], dm._alphas_h[t], dm._abar_h[t])
-                    z = torch.randn_like(x)
-                    out = torch.empty_like(x)
-                    call("ddpm_reverse_step", C.c_void_p(x.data_ptr()), C.c_void_p(eps.data_ptr()), None, 0.0, C.c_void_p(z.data_ptr()),
-                         c1, c2, c3, C.c_void_p(out.data_ptr()), x.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                    if args.noise == "philox":          # drawn inside the fused last kernel
+                        step = dict(c1=c1, c2=c2, c3=c3, noise_mode=2, z=None, seed=1234 + rank, call=t)
+                    else:                               # what sample() does by default: torch's device generator
+                        step = dict(c1=c1, c2=c2, c3=c3, noise_mode=1, z=torch.randn_like(x))
+                    out = model.denoise_step(x, tt, labels, step)     # UNet forward whose last layer is fused with the update
                 state["x"], state["t"] = out, (t - 1 if t > 1 else T_FULL - 1)
         else:
             model.train()
@@ -360,8 +383,9 @@ class Job:
                            share_of_step=round(v[1] / prof_steps / sec_per_step, 3)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
         cfg = {"workload": wl["name"], "per_gpu_batch": self.B, "global_batch": total_b}
         if self.sampling:
-            cfg.update(T=T_FULL, step="one denoising step (UNet eval forward + noise draw + fused reverse-step kernel); "
-                                      "images/s = global_batch / (T * seconds_per_step)")
+            cfg.update(T=T_FULL, step="one denoising step as DiffusionModel.sample() runs it: noise draw (%s) + UNet eval forward whose final "
+                                      "1x1 conv is fused with the reverse-step update; images/s = global_batch / (T * seconds_per_step)"
+                                      % ("in-kernel Philox" if args.noise == "philox" else "torch.randn_like"))
         else:
             bn = "global batch statistics (all-reduce of per-rank sums, forward and backward)" if (multi and args.batchnorm == "sync") \
                 else "per-rank batch statistics"
@@ -421,16 +445,24 @@ def main():
     ap.add_argument("--profile-stride", type=int, default=7,
                     help="bracket every N-th MFMA launch of the timed steps with HIP events (1 = all; events cost GPU time)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
-    ap.add_argument("--allreduce", default="flat", choices=["bucketed", "flat"],
+    ap.add_argument("--allreduce", default="bucketed", choices=["bucketed", "flat"],
                     help="data-parallel training: gradient buckets all-reduced while the backward runs, or one flat all-reduce after it")
     ap.add_argument("--bucket-mb", type=int, default=8, help="gradient bucket size in MiB (bucketed all-reduce)")
     ap.add_argument("--batchnorm", default="local", choices=["local", "sync"],
                     help="data-parallel training: per-rank batch statistics, or global ones (the reference's semantics at the global batch)")
+    ap.add_argument("--noise", default="torch", choices=["torch", "philox"],
+                    help="sampling: per-step noise from torch.randn_like (sample()'s default) or drawn inside the fused last kernel")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--settle", type=float, default=1.5, help="seconds of untimed steps before the warm-up steps")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the multi-GPU code path (process group, collectives) "
                                                               "even with one rank")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: native libraries that print there (RCCL's version banner at communicator
+    # creation, gloo's connection notes) are sent to stderr by pointing fd 1 at fd 2; the line goes to the saved fd
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -516,7 +548,7 @@ def main():
             out["sampling"] = {k: samp[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "kernels", "hbm_kernel",
                                                     "full_call", "cpu_baseline") if k in samp}
             out.setdefault("hbm_kernel", samp.get("hbm_kernel"))
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if ctx["dist"] is not None:
         ctx["dist"].destroy_process_group()
 

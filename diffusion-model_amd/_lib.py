@@ -65,6 +65,10 @@ _SIGNATURES = {
     "ddpm_bn_stats": [P, I32, I64, I32, F32, F32, P, P, P, P, P, P],
     "ddpm_bn_stats_noalloc_max_channels": [],
     "ddpm_bn_stats_noalloc": [P, I32, I64, I32, F32, F32, P, P, P, P, P],
+    "ddpm_bn_partial_sums": [P, I32, I64, I32, P, P, P],
+    "ddpm_bn_finalize_stats": [P, I64, I32, F32, F32, P, P, P, P, P],
+    "ddpm_bn_bwd_sums": [P, I32, P, I32, P, I32, P, P, P, P, I32, I64, I32, P, P, P],
+    "ddpm_bn_bwd_apply": [P, I32, P, I32, P, I32, P, P, P, P, P, I64, I32, I64, I32, P, P, I32, P, I32, P, P],
     "ddpm_bn_apply_fwd": [P, I32, P, P, P, P, P, I32, P, I32, P, I32, I32, I32, I32, P],
     "ddpm_bn_bwd": [P, I32, P, I32, P, I32, P, P, P, P, I32, I64, I32, P, P, P, P, I32, P, I32, P, I32, P, P],
     "ddpm_colsum": [P, I32, I32, I64, I32, P, I32, P, P],

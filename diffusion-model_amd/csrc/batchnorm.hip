@@ -264,15 +264,15 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
                                                                  int ldd, const float* __restrict__ res, int ldr,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                  const float* __restrict__ w, const float* __restrict__ b,
-                                                                 const float* __restrict__ sums, int act, int64_t rows, int c,
-                                                                 float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddr,
-                                                                 double* __restrict__ colsum_partial) {
+                                                                 const float* __restrict__ sums, int act, int64_t rows, int64_t stat_rows,
+                                                                 int c, float* __restrict__ dx, int lddx, float* __restrict__ dres,
+                                                                 int lddr, double* __restrict__ colsum_partial) {
     __shared__ double sh[kThreads * 8];
     const Lanes l = lanes_for(c);
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (l.active) {
         const int ch = l.c4 * 4;
-        const float inv_m = 1.0f / static_cast<float>(rows);
+        const float inv_m = 1.0f / static_cast<float>(stat_rows);   // rows the statistics were taken over (all ranks' rows when synchronised)
         float mu_[4], is_[4], w_[4], b_[4], kb[4], kw[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -307,6 +307,39 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
 #pragma unroll
             for (int e = 0; e < 4; ++e) colsum_partial[static_cast<int64_t>(blockIdx.x) * c + l.c4 * 4 + e] = v[e];
         }
+    }
+}
+
+// The two-quantity reductions above, finished to RAW float64 sums instead of statistics: sums[0..c) and sums[c..2c)
+// (sum x | sum x^2, or sum dz | sum dz*xhat). What a data-parallel job all-reduces across ranks before finalising.
+__global__ __launch_bounds__(kThreads) void pair_sums_final_kernel(const double* __restrict__ partial, int nblk, int c,
+                                                                    double* __restrict__ sums) {
+    __shared__ double sh[kThreads];
+    const int ch = blockIdx.x * kFin + (threadIdx.x % kFin);
+    const bool valid = ch < c;
+    const double s = sliced_sum(partial, nblk, 2 * static_cast<int64_t>(c), ch, valid, sh);
+    const double ss = sliced_sum(partial, nblk, 2 * static_cast<int64_t>(c), c + ch, valid, sh);
+    if (threadIdx.x / kFin != 0 || !valid) return;
+    sums[ch] = s;
+    sums[c + ch] = ss;
+}
+
+// mean / invstd / running statistics from (possibly all-reduced) sums over total_rows rows: the arithmetic of
+// bn_stats_final_kernel, one thread per channel.
+__global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const double* __restrict__ sums, int64_t rows, int c, float eps, float momentum,
+                                                                float* __restrict__ mean, float* __restrict__ invstd,
+                                                                float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const double m = sums[ch] / static_cast<double>(rows);
+    double var = sums[c + ch] / static_cast<double>(rows) - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[ch] = static_cast<float>(m);
+    invstd[ch] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    if (running_mean) {
+        const double unbiased = rows > 1 ? var * static_cast<double>(rows) / static_cast<double>(rows - 1) : var;
+        running_mean[ch] = static_cast<float>((1.0 - momentum) * running_mean[ch] + momentum * m);
+        running_var[ch] = static_cast<float>((1.0 - momentum) * running_var[ch] + momentum * unbiased);
     }
 }
 
@@ -463,10 +496,65 @@ extern "C" int ddpm_bn_bwd(const float* x, int ldx, const float* dout, int ldd, 
     const int nb = partial_blocks(rows, c);
     bn_bwd_partial_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, act, rows, c, workspace);
     bn_bwd_final_kernel<<<(c + kFin - 1) / kFin, kThreads, 0, s>>>(workspace, nb, c, accumulate, dw, db, sums);
-    bn_bwd_apply_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, sums, act, rows, c, dx, lddx,
+    bn_bwd_apply_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, sums, act, rows, rows, c, dx, lddx,
                                                 dresidual, lddr, dconv_bias ? workspace : nullptr);
     if (dconv_bias) colsum_final_kernel<<<dim3((c + kFin - 1) / kFin, 1), kThreads, 0, s>>>(workspace, 1, nb, c, accumulate, dconv_bias);
     return ddpm::check_launch("bn_bwd");
+}
+
+// ---- the same BatchNorm in two halves, for data-parallel training with GLOBAL batch statistics ----------------
+extern "C" int ddpm_bn_partial_sums(const float* x, int ldx, int64_t rows, int c, double* workspace, double* sums, void* stream) {
+    DDPM_REQUIRE(x && workspace && sums && rows > 0 && c > 0 && (c & 3) == 0 && c <= 1024);
+    DDPM_REQUIRE((ldx & 3) == 0 && ldx >= c && ddpm::aligned16(x));
+    const int nb = partial_blocks(rows, c);
+    bn_stats_partial_kernel<<<nb, kThreads, 0, as_stream(stream)>>>(x, ldx, rows, c, workspace);
+    pair_sums_final_kernel<<<(c + kFin - 1) / kFin, kThreads, 0, as_stream(stream)>>>(workspace, nb, c, sums);
+    return ddpm::check_launch("bn_partial_sums");
+}
+
+extern "C" int ddpm_bn_finalize_stats(const double* sums, int64_t total_rows, int c, float eps, float momentum, float* mean, float* invstd,
+                                      float* running_mean, float* running_var, void* stream) {
+    DDPM_REQUIRE(sums && mean && invstd && total_rows > 0 && c > 0);
+    DDPM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    bn_finalize_kernel<<<(c + kThreads - 1) / kThreads, kThreads, 0, as_stream(stream)>>>(sums, total_rows, c, eps, momentum, mean, invstd,
+                                                                                          running_mean, running_var);
+    return ddpm::check_launch("bn_finalize_kernel");
+}
+
+extern "C" int ddpm_bn_bwd_sums(const float* x, int ldx, const float* dout, int ldd, const float* residual, int ldr, const float* mean,
+                                const float* invstd, const float* w, const float* b, int act, int64_t rows, int c, double* workspace,
+                                double* sums, void* stream) {
+    DDPM_REQUIRE(x && dout && mean && invstd && w && b && workspace && sums && rows > 0);
+    DDPM_REQUIRE(c > 0 && (c & 3) == 0 && c <= 1024);
+    DDPM_REQUIRE((ldx & 3) == 0 && (ldd & 3) == 0 && ldx >= c && ldd >= c);
+    DDPM_REQUIRE(ddpm::aligned16(x) && ddpm::aligned16(dout) && ddpm::aligned16(mean) && ddpm::aligned16(invstd));
+    DDPM_REQUIRE(ddpm::aligned16(w) && ddpm::aligned16(b));
+    DDPM_REQUIRE(!residual || ((ldr & 3) == 0 && ldr >= c && ddpm::aligned16(residual)));
+    DDPM_REQUIRE(act >= DDPM_ACT_NONE && act <= DDPM_ACT_GELU);
+    hipStream_t s = as_stream(stream);
+    const int nb = partial_blocks(rows, c);
+    bn_bwd_partial_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, act, rows, c, workspace);
+    pair_sums_final_kernel<<<(c + kFin - 1) / kFin, kThreads, 0, s>>>(workspace, nb, c, sums);
+    return ddpm::check_launch("bn_bwd_sums");
+}
+
+extern "C" int ddpm_bn_bwd_apply(const float* x, int ldx, const float* dout, int ldd, const float* residual, int ldr, const float* mean,
+                                 const float* invstd, const float* w, const float* b, const float* sums, int64_t total_rows, int act,
+                                 int64_t rows, int c, double* workspace, float* dx, int lddx, float* dresidual, int lddr,
+                                 float* dconv_bias, void* stream) {
+    DDPM_REQUIRE(x && dout && mean && invstd && w && b && sums && dx && rows > 0 && total_rows >= rows);
+    DDPM_REQUIRE(c > 0 && (c & 3) == 0 && c <= 1024 && (!dconv_bias || workspace));
+    DDPM_REQUIRE((ldx & 3) == 0 && (ldd & 3) == 0 && (lddx & 3) == 0 && ldx >= c && ldd >= c && lddx >= c);
+    DDPM_REQUIRE(ddpm::aligned16(x) && ddpm::aligned16(dout) && ddpm::aligned16(dx));
+    DDPM_REQUIRE(!residual || ((ldr & 3) == 0 && ldr >= c && ddpm::aligned16(residual)));
+    DDPM_REQUIRE(!dresidual || ((lddr & 3) == 0 && lddr >= c && ddpm::aligned16(dresidual)));
+    DDPM_REQUIRE(act >= DDPM_ACT_NONE && act <= DDPM_ACT_GELU);
+    hipStream_t s = as_stream(stream);
+    const int nb = partial_blocks(rows, c);
+    bn_bwd_apply_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, sums, act, rows, total_rows, c, dx,
+                                                lddx, dresidual, lddr, dconv_bias ? workspace : nullptr);
+    if (dconv_bias) colsum_final_kernel<<<dim3((c + kFin - 1) / kFin, 1), kThreads, 0, s>>>(workspace, 1, nb, c, 0, dconv_bias);
+    return ddpm::check_launch("bn_bwd_apply");
 }
 
 extern "C" int ddpm_colsum(const float* x, int ld, int groups, int64_t rows_per_group, int c, double* workspace, int accumulate,

@@ -26,7 +26,14 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _dist_active():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 class TrainMixin:
+    sync_bn = False     # data-parallel training: BatchNorm over the GLOBAL batch (statistics all-reduced across ranks)
+    grad_sink = None    # data-parallel training: where the backward puts parameter gradients (parallel.BucketedGradientAverager)
     _s2 = None                                                      # second stream of the backward pass (weight gradients)
     _main_stream = None                                             # the stream the backward itself runs on (set when _s2 is used)
     _use_side = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # diagnostic switch: "0" keeps the backward on one stream
@@ -47,6 +54,28 @@ class TrainMixin:
         split = (m > 64 or n > 64) and os.environ.get("DDPM_CONV_MATH") != "fp32"
         return f"conv_wgrad<{kind},{'split-bf16' if split else 'fp32'}>"
 
+    # ------------------------------------------------------------------ gradient storage
+    def _gnew(self, shape, dev, zero=False):
+        """Storage of one parameter gradient (or of a fused group of them): a fresh tensor, or, in data-parallel
+        training, the next slice of the averager's flat buffer, so that buckets of finished gradients can be
+        all-reduced while the rest of the backward is still running and nothing is copied afterwards."""
+        shape = tuple(shape) if isinstance(shape, (tuple, list, torch.Size)) else (int(shape),)
+        sink = self.grad_sink
+        if sink is None:
+            return (torch.zeros if zero else torch.empty)(shape, device=dev, dtype=torch.float32)
+        n = 1
+        for s in shape:
+            n *= s
+        t = sink.alloc(n, dev).view(shape)
+        if zero:
+            t.zero_()
+        return t
+
+    def _gflush(self):
+        """A point of the backward at which every gradient handed out so far has all its kernels enqueued."""
+        if self.grad_sink is not None:
+            self.grad_sink.flush(self)
+
     # ------------------------------------------------------------------ forward pieces
     def _conv_bn_fwd(self, V, src, conv_key, bn_key, cout, act, out, residual=None, temb=None, first=None):
         """conv3x3 (+bias) -> batch statistics -> normalise/affine (+residual) -> act (+temb)."""
@@ -62,15 +91,27 @@ class TrainMixin:
             self.conv3x3(src, self.packed_conv3(conv_key), cout, raw, None, bias)
         mean = torch.empty(cout, device=dev, dtype=torch.float32)
         invstd = torch.empty(cout, device=dev, dtype=torch.float32)
-        call("ddpm_bn_stats", raw.ptr, raw.ld, b * h * w, cout, BN_EPS, BN_MOMENTUM, _ptr(self._workspace(dev)), _ptr(mean),
-             _ptr(invstd), _ptr(self.T(bn_key + ".running_mean")), _ptr(self.T(bn_key + ".running_var")), _stream())
+        stat_rows = b * h * w
+        if self.sync_bn and _dist_active():
+            # global-batch statistics: this rank's sums are all-reduced, then finalised on every rank. Every rank
+            # holds the same number of samples (the batch axis is cut evenly), so the global row count needs no exchange.
+            from . import parallel
+            sums = torch.empty(2 * cout, device=dev, dtype=torch.float64)
+            call("ddpm_bn_partial_sums", raw.ptr, raw.ld, stat_rows, cout, _ptr(self._workspace(dev)), _ptr(sums), _stream())
+            parallel.all_reduce_(sums)
+            stat_rows = stat_rows * parallel.world_size()
+            call("ddpm_bn_finalize_stats", _ptr(sums), stat_rows, cout, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
+                 _ptr(self.T(bn_key + ".running_mean")), _ptr(self.T(bn_key + ".running_var")), _stream())
+        else:
+            call("ddpm_bn_stats", raw.ptr, raw.ld, stat_rows, cout, BN_EPS, BN_MOMENTUM, _ptr(self._workspace(dev)), _ptr(mean),
+                 _ptr(invstd), _ptr(self.T(bn_key + ".running_mean")), _ptr(self.T(bn_key + ".running_var")), _stream())
         self._nbt.append(self.T(bn_key + ".num_batches_tracked"))    # incremented together at the end of the forward
         self._stats_written += [self.T(bn_key + ".running_mean"), self.T(bn_key + ".running_var")]
         call("ddpm_bn_apply_fwd", raw.ptr, raw.ld, _ptr(mean), _ptr(invstd), _ptr(self.T(bn_key + ".weight")),
              _ptr(self.T(bn_key + ".bias")), residual.ptr if residual is not None else None,
              residual.ld if residual is not None else 0, _ptr(temb), act, out.ptr, out.ld, b, h * w, cout, _stream())
         return dict(kind="conv_bn", src=src, raw=raw, mean=mean, invstd=invstd, conv=conv_key, bn=bn_key, act=act,
-                    residual=residual, first=first, cout=cout)
+                    residual=residual, first=first, cout=cout, stat_rows=stat_rows)
 
     def _double_conv_fwd(self, V, src, key, cout, out, temb=None, first=None):
         p = key + ".double_conv"
@@ -206,18 +247,33 @@ class TrainMixin:
         res = rec["residual"]
         dres = V(torch.empty((b, h, w, cout), device=dev, dtype=torch.float32)) if res is not None else None
         bn, conv = rec["bn"], rec["conv"]
-        dw, db, dcb = (torch.empty(cout, device=dev, dtype=torch.float32) for _ in range(3))
-        call("ddpm_bn_bwd", raw.ptr, raw.ld, dout.ptr, dout.ld, res.ptr if res is not None else None, res.ld if res is not None else 0,
-             _ptr(rec["mean"]), _ptr(rec["invstd"]), _ptr(self.T(bn + ".weight")), _ptr(self.T(bn + ".bias")), rec["act"], rows, cout,
-             _ptr(ws), _ptr(self._sums), _ptr(dw), _ptr(db), 0, draw.ptr, draw.ld, dres.ptr if dres is not None else None,
-             dres.ld if dres is not None else 0, _ptr(dcb), _stream())
+        dw, db, dcb = (self._gnew(cout, dev) for _ in range(3))
+        rp, rl = (res.ptr, res.ld) if res is not None else (None, 0)
+        dp, dl = (dres.ptr, dres.ld) if dres is not None else (None, 0)
+        if rec["stat_rows"] != rows:
+            # statistics were taken over all ranks' rows: the two sums of the backward are all-reduced as well
+            from . import parallel
+            sums = torch.empty(2 * cout, device=dev, dtype=torch.float64)
+            call("ddpm_bn_bwd_sums", raw.ptr, raw.ld, dout.ptr, dout.ld, rp, rl, _ptr(rec["mean"]), _ptr(rec["invstd"]),
+                 _ptr(self.T(bn + ".weight")), _ptr(self.T(bn + ".bias")), rec["act"], rows, cout, _ptr(ws), _ptr(sums), _stream())
+            db.copy_(sums[:cout])                              # this rank's share of the parameter gradients
+            dw.copy_(sums[cout:])
+            parallel.all_reduce_(sums)
+            call("ddpm_bn_bwd_apply", raw.ptr, raw.ld, dout.ptr, dout.ld, rp, rl, _ptr(rec["mean"]), _ptr(rec["invstd"]),
+                 _ptr(self.T(bn + ".weight")), _ptr(self.T(bn + ".bias")), _ptr(sums.float()), rec["stat_rows"], rec["act"], rows, cout,
+                 _ptr(ws), draw.ptr, draw.ld, dp, dl, _ptr(dcb), _stream())
+        else:
+            call("ddpm_bn_bwd", raw.ptr, raw.ld, dout.ptr, dout.ld, rp, rl, _ptr(rec["mean"]), _ptr(rec["invstd"]),
+                 _ptr(self.T(bn + ".weight")), _ptr(self.T(bn + ".bias")), rec["act"], rows, cout, _ptr(ws), _ptr(self._sums), _ptr(dw),
+                 _ptr(db), 0, draw.ptr, draw.ld, dp, dl, _ptr(dcb), _stream())
         grads[bn + ".weight"], grads[bn + ".bias"], grads[conv + ".bias"] = dw, db, dcb
         wt = self.T(conv + ".weight")
-        gw = torch.empty_like(wt)
+        gw = self._gnew(wt.shape, dev)
         if rec["first"] is not None:
             img = rec["first"]
             call("ddpm_conv3x3_first_wgrad", draw.ptr, draw.ld, _ptr(img), _ptr(ws), _ptr(gw), b, img.shape[1], h, w, cout, _stream())
             grads[conv + ".weight"] = gw
+            self._gflush()
             return None, dres
         src = rec["src"]
         packed = torch.empty(wt.numel(), device=dev, dtype=torch.float32)
@@ -225,6 +281,7 @@ class TrainMixin:
             self._launch(self._wgrad_label("conv3x3", cout, src.c), 2.0 * rows * cout * 9 * src.c, "ddpm_conv3x3_wgrad", draw.ptr, draw.ld, cout, src.ptr,
                          src.ld, src.c, b, h, w, _ptr(packed), _ptr(gw), _stream())
         grads[conv + ".weight"] = gw
+        self._gflush()
         dsrc = None
         if need_dsrc:
             dsrc = V(torch.empty((b, h, w, src.c), device=dev, dtype=torch.float32))
@@ -248,7 +305,7 @@ class TrainMixin:
         lq = 2 * dqp + c
         dq = c // 8
         dqkv = V(torch.empty((b, h, w, lq), device=dev, dtype=torch.float32))
-        dgamma = torch.empty(1, device=dev, dtype=torch.float32)
+        dgamma = self._gnew(1, dev)
         e = torch.empty((b, n), device=dev, dtype=torch.float32)
         ws = self._workspace(dev)
         x3 = os.environ.get("DDPM_CONV_MATH", "") != "fp32" and (c, dqp) in ((64, 8), (128, 16), (256, 32))
@@ -256,12 +313,13 @@ class TrainMixin:
                      _ptr(rec["raw"]), _ptr(rec["lse"]), _ptr(self.T(key + ".gamma")), _ptr(ws), _ptr(e), dqkv.ptr, _ptr(dgamma), b, n, c,
                      dqp, _stream())
         grads[key + ".gamma"] = dgamma
-        gw = torch.empty((lq, c), device=dev, dtype=torch.float32)
+        gw = self._gnew((lq, c), dev)                        # query | key | value weight gradients, one fused slice
         with self._side(dqkv.buf, gw):
             self._launch(self._wgrad_label("conv1x1", lq, c), 2.0 * b * n * lq * c, "ddpm_conv1x1_wgrad", dqkv.ptr, lq, lq, x.ptr, x.ld, c, b * n,
                          _ptr(gw), _stream())
-        gb = torch.empty(lq, device=dev, dtype=torch.float32)
+        gb = self._gnew(lq, dev)
         call("ddpm_colsum", dqkv.ptr, lq, 1, b * n, lq, _ptr(ws), 0, _ptr(gb), _stream())
+        self._gflush()
         for name, lo, cnt in (("query", 0, dq), ("key", dqp, dq), ("value", 2 * dqp, c)):
             grads[f"{key}.{name}.weight"] = gw[lo:lo + cnt].reshape(self.T(f"{key}.{name}.weight").shape)
             grads[f"{key}.{name}.bias"] = gb[lo:lo + cnt]
@@ -296,8 +354,8 @@ class TrainMixin:
         # final 1x1 conv
         hfin = tape["final_in"]
         dh = V(torch.empty((B, H, W, bc), device=dev, dtype=torch.float32))
-        gw = torch.empty_like(self.T("final_conv.weight"))
-        gb = torch.empty_like(self.T("final_conv.bias"))
+        gw = self._gnew(self.T("final_conv.weight").shape, dev)
+        gb = self._gnew(self.T("final_conv.bias").shape, dev)
         call("ddpm_conv1x1_final_bwd", _ptr(dout), hfin.ptr, hfin.ld, _ptr(self.T("final_conv.weight")), _ptr(ws), dh.ptr, dh.ld,
              _ptr(gw), _ptr(gb), B, H, W, bc, self.cout_final, _stream())
         grads["final_conv.weight"], grads["final_conv.bias"] = gw, gb
@@ -322,15 +380,16 @@ class TrainMixin:
             off_y, off_x = (oh - 2 * h) // 2, (ow - 2 * w) // 2
             ukey = key + ".up"
             wt = self.T(ukey + ".weight")
-            guw, packed = torch.empty_like(wt), torch.empty(wt.numel(), device=dev, dtype=torch.float32)
+            guw, packed = self._gnew(wt.shape, dev), torch.empty(wt.numel(), device=dev, dtype=torch.float32)
             with self._side(dcat.buf, packed, guw):
                 call("ddpm_convT2x2_wgrad", dup.ptr, dup.ld, cs, oh, ow, off_y, off_x, up_in.ptr, up_in.ld, up_in.c, b, h, w, _ptr(packed),
                      _ptr(guw), _stream())
             y0, x0 = max(off_y, 0), max(off_x, 0)
             y1, x1 = min(oh, off_y + 2 * h), min(ow, off_x + 2 * w)
-            gub = torch.empty(cs, device=dev, dtype=torch.float32)
+            gub = self._gnew(cs, dev)
             call("ddpm_colsum_window", dup.ptr, dup.ld, b, oh, ow, y0, x0, y1 - y0, x1 - x0, cs, _ptr(ws), _ptr(gub), _stream())
             grads[ukey + ".weight"], grads[ukey + ".bias"] = guw, gub
+            self._gflush()
             dh = V(torch.empty((b, h, w, up_in.c), device=dev, dtype=torch.float32))
             d = ConvDesc(batch=b, in_h=h, in_w=w, c1=cs, ld1=dup.ld, c2=0, ld2=0, cout=up_in.c, ldo=dh.ld, act=ACT_NONE, ldr=0,
                          out_h=oh, out_w=ow, off_y=off_y, off_x=off_x)
@@ -367,21 +426,22 @@ class TrainMixin:
             g.y = y.data_ptr()
             g.label_table = self.T("label_embedding.weight").data_ptr()
             g.n_classes = self.T("label_embedding.weight").shape[0]
-            outs["label_embedding.weight"] = torch.zeros_like(self.T("label_embedding.weight"))
+            outs["label_embedding.weight"] = self._gnew(self.T("label_embedding.weight").shape, dev, zero=True)
             g.dlabel_table = outs["label_embedding.weight"].data_ptr()
         for k in range(4):
             g.ch[k] = chans[k]
             g.dtemb[k] = dtemb[k].data_ptr()
             for nm, field in ((f"time_fc{k + 1}.weight", g.dw), (f"time_fc{k + 1}.bias", g.db)):
-                outs[nm] = torch.empty_like(self.T(nm))
+                outs[nm] = self._gnew(self.T(nm).shape, dev)
                 field[k] = outs[nm].data_ptr()
             if y is not None:
                 g.lw[k] = self.T(f"label_emdedding_fc{k + 1}.weight").data_ptr()
                 for nm, field in ((f"label_emdedding_fc{k + 1}.weight", g.dlw), (f"label_emdedding_fc{k + 1}.bias", g.dlb)):
-                    outs[nm] = torch.empty_like(self.T(nm))
+                    outs[nm] = self._gnew(self.T(nm).shape, dev)
                     field[k] = outs[nm].data_ptr()
         call("ddpm_time_embed_bwd", C.byref(g), _stream())
         grads.update(outs)
+        self._gflush()
         if self._s2 is not None:
             torch.cuda.current_stream().wait_stream(self._s2)
         return grads
@@ -407,6 +467,12 @@ class UNetFunction(torch.autograd.Function):
     def backward(ctx, dout, *unused):
         if dout is None:                   # nothing downstream depends on the prediction
             return (None,) * (5 + len(ctx.names))
-        grads = ctx.engine.backward(ctx.tape, dout)
+        eng = ctx.engine
+        grads = eng.backward(ctx.tape, dout)
         ctx.tape = None
+        sink = eng.grad_sink
+        if sink is not None and sink.takes_over(grads):
+            # the averager owns the gradients (slices of its flat buffer, buckets already in flight): it assigns
+            # .grad itself when it finishes, so autograd gets nothing to accumulate (and nothing to copy)
+            return (None,) * (5 + len(ctx.names))
         return (None, None, None, None, None, *[grads.get(n) for n in ctx.names])

@@ -96,3 +96,122 @@ def sample_sharded(diffusion, x_shape, device, gather=True, noise=None, group=No
     for i, (_, t) in enumerate(ref):
         out.append((torch.cat([g[i][0] for g in gathered if g], dim=0), t))
     return out
+
+
+def world_size(group=None):
+    return _world(group)[0]
+
+
+class BucketedGradientAverager:
+    """Data-parallel gradient averaging that overlaps with the backward pass.
+
+    The UNet's hand-written backward (engine_train.TrainMixin.backward) asks this object for the storage of every
+    parameter gradient, in the order it produces them (decoder first). The storage is consecutive slices of ONE
+    persistent flat buffer; at the backward's flush points every slice handed out so far has all its kernels enqueued,
+    and once `bucket_bytes` of such gradients have accumulated they are all-reduced asynchronously (RCCL on its own
+    stream) while the backward goes on. finish() waits for the buckets, scales to the mean and points every
+    parameter's .grad at its slice: no concatenation, no copy back, and only the last bucket's all-reduce is exposed.
+
+    The first step runs in recording mode (the gradients are ordinary tensors, averaged by average_gradients) to
+    learn the sequence of slice sizes; the flat buffer is built from it. Usage per step:
+        loss.backward(); averager.finish(); optimizer.step()
+    """
+
+    ALIGN = 64      # floats: every slice starts on a 256-byte boundary
+
+    def __init__(self, model, bucket_bytes=8 << 20, group=None):
+        self.model, self.group = model, group
+        self.bucket_floats = max(1, int(bucket_bytes) // 4)
+        self.engine = model._engine
+        self.sizes = None          # slice sizes (floats, aligned) in the order of the backward, once recorded
+        self.flat = None
+        self._recording = []
+        self._reset()
+
+    def attach(self):
+        self.engine.grad_sink = self
+        return self
+
+    def detach(self):
+        if self.engine.grad_sink is self:
+            self.engine.grad_sink = None
+
+    def _reset(self):
+        self._i, self._off, self._sent, self._work, self._grads = 0, 0, 0, [], None
+
+    # ---- called by the engine during the backward ------------------------------------------------
+    def alloc(self, numel, dev):
+        padded = -(-int(numel) // self.ALIGN) * self.ALIGN
+        if self.flat is None:                                  # recording mode
+            self._recording.append(padded)
+            return torch.empty(numel, device=dev, dtype=torch.float32)
+        if self._i >= len(self.sizes) or self.sizes[self._i] != padded:
+            raise RuntimeError("the backward pass asked for gradient storage in a different order or size than when the "
+                               "averager recorded it (model or input structure changed): build a new BucketedGradientAverager")
+        t = self.flat[self._off:self._off + numel]
+        self._i += 1
+        self._off += padded
+        return t
+
+    def flush(self, engine, force=False):
+        if self.flat is None or self._off == self._sent:
+            return
+        if not force and self._off - self._sent < self.bucket_floats:
+            return
+        bucket = self.flat[self._sent:self._off]
+        self._sent = self._off
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if bucket.is_cuda and _host_staged(self.group):       # gloo rehearsal: synchronous, through the host
+            side = getattr(engine, "_s2", None)
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)  # weight gradients are written on the side stream
+            all_reduce_(bucket, group=self.group)
+            self._work.append(None)
+            return
+        if bucket.is_cuda:
+            # gradients are written by two streams (data-gradient chain on the current one, weight gradients on the
+            # engine's side stream): the collective is issued from the side stream after it has caught up with the
+            # current one, so the data-gradient chain itself never waits for it
+            main = torch.cuda.current_stream()
+            side = getattr(engine, "_s2", None)
+            if side is not None and side != main:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._work.append(dist.all_reduce(bucket, group=self.group, async_op=True))
+                return
+        self._work.append(dist.all_reduce(bucket, group=self.group, async_op=True))
+
+    def takes_over(self, grads):
+        """End of the backward: True when the gradients live in the flat buffer (finish() will assign .grad)."""
+        if self.flat is None:
+            return False
+        self._grads = grads
+        return True
+
+    # ---- called by the training loop after loss.backward() ---------------------------------------
+    def finish(self):
+        world, _ = _world(self.group)
+        if self.flat is None:
+            # recording step: plain tensors, one flat all-reduce; then build the persistent buffer
+            average_gradients(list(self.model.parameters()), group=self.group)
+            if self._recording:
+                self.sizes = list(self._recording)
+                dev = next(self.model.parameters()).device
+                self.flat = torch.zeros(sum(self.sizes), device=dev, dtype=torch.float32)
+            self._recording = []
+            self._reset()
+            return
+        if self._grads is None:
+            raise RuntimeError("finish() without a backward pass through the UNet")
+        self.flush(self.engine, force=True)
+        for w in self._work:
+            if w is not None:
+                w.wait()                                       # the current stream waits for the collective; the host does not
+        if world > 1:
+            self.flat.div_(world)
+        for name, p in self.model.named_parameters():
+            g = self._grads.get(name)
+            if g is not None:
+                p.grad = g
+        self._reset()

@@ -333,6 +333,29 @@ int ddpm_bn_bwd(const float* x, int ldx, const float* dout, int ldd, const float
                 int accumulate, float* dx, int lddx, float* dresidual, int lddr, float* dconv_bias,
                 void* stream);
 
+/* The same BatchNorm in two halves, for data-parallel training with GLOBAL batch statistics (the
+ * reference's semantics at the global batch: one process normalises over all samples,
+ * second-iteration/unet.py:17,21,33). Between the halves the caller all-reduces (sum) the 2*c doubles
+ * across ranks -- with torch.distributed over RCCL; the library itself holds no communicator.
+ *   forward : ddpm_bn_partial_sums -> sums = [sum x | sum x^2] of this rank's rows; all-reduce;
+ *             ddpm_bn_finalize_stats(sums, total_rows = rows of all ranks) -> mean, invstd, running
+ *             statistics; then ddpm_bn_apply_fwd as usual.
+ *   backward: ddpm_bn_bwd_sums -> sums = [sum dz | sum dz*xhat] of this rank's rows (their float values
+ *             are this rank's db | dw); all-reduce; ddpm_bn_bwd_apply with the reduced sums (as floats)
+ *             and total_rows -> dx (+ dresidual, dconv_bias = column sums of this rank's dx).
+ * With one rank the two halves compute exactly what ddpm_bn_stats / ddpm_bn_bwd compute. */
+int ddpm_bn_partial_sums(const float* x, int ldx, int64_t rows, int c, double* workspace, double* sums,
+                         void* stream);
+int ddpm_bn_finalize_stats(const double* sums, int64_t total_rows, int c, float eps, float momentum,
+                           float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
+int ddpm_bn_bwd_sums(const float* x, int ldx, const float* dout, int ldd, const float* residual, int ldr,
+                     const float* mean, const float* invstd, const float* w, const float* b, int act,
+                     int64_t rows, int c, double* workspace, double* sums, void* stream);
+int ddpm_bn_bwd_apply(const float* x, int ldx, const float* dout, int ldd, const float* residual, int ldr,
+                      const float* mean, const float* invstd, const float* w, const float* b,
+                      const float* sums, int64_t total_rows, int act, int64_t rows, int c, double* workspace,
+                      float* dx, int lddx, float* dresidual, int lddr, float* dconv_bias, void* stream);
+
 /* out[g][c] (+)= sum of x over the rows of group g (groups of rows_per_group consecutive pixels):
  * groups = batch gives the gradient of a broadcast time-embedding add, groups = 1 a bias gradient. */
 int ddpm_colsum(const float* x, int ld, int groups, int64_t rows_per_group, int c, double* workspace,

@@ -1,0 +1,151 @@
+"""Worker of tests/test_gpu_dp.py: one rank of a 2-rank data-parallel job whose ranks SHARE GPU 0 (gloo moves the
+collectives through the host; the GPU work is the real HIP path). Checks, against the reference's golden vectors:
+  1. global-batch BatchNorm + averaged gradients of a sharded batch == the reference's full-batch gradients;
+  2. the bucketed averager (recording step, then buckets from inside the backward) == the flat all-reduce;
+  3. 10 Adam steps sharded 2 + 2 reproduce the reference's single-process loss trace (batch 4);
+  4. sharded sampling with sliced injected noise == unsharded sampling, bit for bit.
+Prints DP_WORKER_OK on rank 0."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from seeding import seeded_ints, seeded_state_dict, seeded_tensor  # noqa: E402
+import diffusion_model_amd as pkg  # noqa: E402
+from diffusion_model_amd import parallel  # noqa: E402
+from diffusion_model_amd.optim import Adam  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def build(variant, seed):
+    U = pkg.make_unet_class(variant)
+    m = U(1, 1, 8, 16) if variant < 3 else U(3, 3, 8, 16, num_classes=10)
+    m.load_state_dict(seeded_state_dict(m.state_dict(), seed))
+    return m.cuda()
+
+
+def mean_over_ranks(v):
+    t = torch.tensor([v], dtype=torch.float64)
+    dist.all_reduce(t)
+    return t.item() / dist.get_world_size()
+
+
+def check_grads(m, g, tag, what):
+    worst = []
+    for k, p in m.named_parameters():
+        ref = torch.from_numpy(g[f"{tag}_grad::{k}"])
+        got = p.grad.cpu() if p.grad is not None else torch.zeros_like(ref)
+        err = (got - ref).abs().max().item()
+        worst.append((err / (2e-3 * ref.abs().max().item() + 5e-6), k, err))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 1.0, (what, worst[:6])
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert world == 2
+    torch.cuda.set_device(0)
+
+    # ---- 1 + 2: gradients of a sharded batch with global-batch BatchNorm ---------------------------------------
+    g = np.load(os.path.join(GOLDEN, "tiny_unet_v2.npz"))
+    x, t, tgt = (torch.from_numpy(g[f"hw28_{k}"]) for k in ("x", "t", "tgt"))
+    lo, hi = parallel.shard_range(x.shape[0], world, rank)
+    for mode in ("flat", "bucketed"):
+        m = build(2, 2).train()
+        m._engine.sync_bn = True
+        parallel.broadcast_parameters(m)
+        avg = parallel.BucketedGradientAverager(m, bucket_bytes=4096).attach() if mode == "bucketed" else None
+        for step in range(3 if avg else 1):          # bucketed: step 0 records the layout, steps 1-2 run in buckets
+            m.zero_grad()
+            loss = torch.nn.MSELoss()(m(x[lo:hi].cuda(), t[lo:hi].cuda()), tgt[lo:hi].cuda())
+            loss.backward()
+            if avg:
+                avg.finish()
+                assert (avg.flat is not None) and (step == 0 or all(p.grad.untyped_storage().data_ptr() == avg.flat.untyped_storage().data_ptr()
+                                                                       for p in m.parameters()))
+            else:
+                parallel.average_gradients(list(m.parameters()))
+            global_loss = mean_over_ranks(loss.item())
+            assert abs(global_loss - g["hw28_train_loss"][0]) <= 1e-4 * g["hw28_train_loss"][0], (mode, step, global_loss)
+            check_grads(m, g, "hw28", f"{mode} step {step}")
+            if step == 0:                              # running statistics after ONE update are the full batch's
+                for k, v in m.state_dict().items():
+                    if "running_" in k:
+                        ref = torch.from_numpy(g[f"hw28_buf::{k}"])
+                        assert (v.cpu() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()), k
+
+    # per-rank statistics (the default) do NOT reproduce the full-batch gradients: the switch matters
+    m = build(2, 2).train()
+    loss = torch.nn.MSELoss()(m(x[lo:hi].cuda(), t[lo:hi].cuda()), tgt[lo:hi].cuda())
+    loss.backward()
+    parallel.average_gradients(list(m.parameters()))
+    ref = torch.from_numpy(g["hw28_grad::enc1.double_conv.0.weight"])
+    assert (m.enc1.double_conv[0].weight.grad.cpu() - ref).abs().max().item() > 2e-3 * ref.abs().max().item()
+
+    # ---- 3: ten Adam steps, batch 4 cut 2 + 2 --------------------------------------------------------------------
+    gt = np.load(os.path.join(GOLDEN, "training_v2.npz"))
+    m = build(2, 2).train()
+    m._engine.sync_bn = True
+    avg = parallel.BucketedGradientAverager(m, bucket_bytes=16384).attach()
+    dm = pkg.make_diffusion_class(2)(m, pkg.BetaScheduler(1000, device="cuda").get_schedule("linear"), 1000)
+    opt = Adam(m.parameters(), lr=2e-4)
+    losses = []
+    for s in range(10):
+        x0 = seeded_tensor((4, 1, 28, 28), 300, f"x0_{s}", "uniform")[2 * rank:2 * rank + 2].cuda()
+        noise = seeded_tensor((4, 1, 28, 28), 300, f"n_{s}")[2 * rank:2 * rank + 2].cuda()
+        ts = seeded_ints((4,), 1000, 300, f"t_{s}")[2 * rank:2 * rank + 2].cuda()
+        pred = m(dm.add_noise(x0, noise, ts), ts)
+        loss = torch.nn.MSELoss()(pred, noise)
+        opt.zero_grad()
+        loss.backward()
+        avg.finish()
+        opt.step()
+        losses.append(mean_over_ranks(loss.item()))
+    np.testing.assert_allclose(losses, gt["losses"], rtol=2e-3)
+    sd = m.state_dict()
+    for k in ("final_conv.weight", "time_fc3.weight", "dec2.up.weight", "enc2.attention.gamma", "bottleneck.0.double_conv.1.weight"):
+        ref = torch.from_numpy(gt[f"final::{k}"])
+        assert (sd[k].cpu() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item()), k
+    # every rank holds the same parameters after the same averaged updates
+    probe = torch.cat([p.detach().reshape(-1)[:64].cpu() for p in m.parameters()])
+    other = probe.clone()
+    dist.broadcast(other, src=0)
+    assert torch.equal(probe, other)
+
+    # ---- 4: sharded sampling == unsharded sampling ---------------------------------------------------------------
+    m3 = build(3, 3).eval()
+    T, shape = 10, (4, 3, 28, 28)
+    dm3 = pkg.make_diffusion_class(3)(m3, pkg.BetaScheduler(T, device="cuda").get_schedule("linear"), T)
+    xT = seeded_tensor(shape, 9, "xT")
+    zs = [seeded_tensor(shape, 9, f"z{i}") for i in range(T - 1)]
+    labels = torch.tensor([5])
+    with torch.no_grad():
+        sharded = parallel.sample_sharded(dm3, shape, "cuda", noise=(xT, zs), labels=labels, cfg_scale=1.5)
+        whole = dm3.sample(shape, "cuda", noise=(xT, zs), labels=labels, cfg_scale=1.5)
+    assert [s[1] for s in sharded] == [s[1] for s in whole]
+    assert all(torch.equal(a[0], b[0]) for a, b in zip(sharded, whole))
+
+    dist.barrier()
+    if rank == 0:
+        print("DP_WORKER_OK", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    try:
+        main()
+    except BaseException:
+        import traceback
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", f"dp_worker_rank{os.environ.get('RANK', '0')}.err"), "w") as f:
+            traceback.print_exc(file=f)
+        raise

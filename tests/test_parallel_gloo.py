@@ -33,6 +33,59 @@ class ToyDiffusion:
         return stages
 
 
+class ToyEngine:
+    """Stands in for the UNet's backward schedule: asks the averager for gradient storage in a fixed order, fills it,
+    and marks flush points, exactly as engine_train.TrainMixin.backward does (CPU tensors, no streams)."""
+    grad_sink = None
+    _s2 = None
+
+    def __init__(self, model):
+        self.m = model
+
+    def backward(self, scale):
+        grads = {}
+        for i, (name, p) in enumerate(reversed(list(self.m.named_parameters()))):
+            g = self.grad_sink.alloc(p.numel(), p.device).view(p.shape) if self.grad_sink else torch.empty_like(p)
+            g.copy_(torch.full_like(p, scale * (i + 1)))
+            grads[name] = g
+            if self.grad_sink:
+                self.grad_sink.flush(self)
+        if self.grad_sink is not None and self.grad_sink.takes_over(grads):
+            return
+        for name, p in self.m.named_parameters():
+            p.grad = grads[name]
+
+
+class ToyModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a, self.b, self.c = torch.nn.Linear(7, 33), torch.nn.Linear(33, 129), torch.nn.Linear(129, 5)
+        self._engine = ToyEngine(self)
+
+
+def _check_bucketed_averager(rank, world):
+    m = ToyModel()
+    avg = parallel.BucketedGradientAverager(m, bucket_bytes=2048).attach()
+    names = [n for n, _ in m.named_parameters()]
+    mean_scale = sum(r + 1 for r in range(world)) / world
+    for step in range(3):                                   # step 0 records the layout, steps 1-2 use the flat buffer
+        m.zero_grad()
+        m._engine.backward(float(rank + 1))
+        avg.finish()
+        for i, name in enumerate(reversed(names)):
+            g = dict(m.named_parameters())[name].grad
+            assert torch.allclose(g, torch.full_like(g, mean_scale * (i + 1))), (step, name)
+        if step > 0:
+            assert all(p.grad.untyped_storage().data_ptr() == avg.flat.untyped_storage().data_ptr() for p in m.parameters())
+            assert all(p.grad.data_ptr() % 256 == avg.flat.data_ptr() % 256 for p in m.parameters())   # 256-byte aligned slices
+    # a backward that asks for other sizes than the recorded ones is refused, not silently mis-sliced
+    m.c = torch.nn.Linear(129, 6)
+    with pytest.raises(RuntimeError, match="different order or size"):
+        m._engine.backward(1.0)
+    avg.detach()
+    assert m._engine.grad_sink is None
+
+
 def _worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,6 +103,7 @@ def _worker(rank, world, port, tmp):
         assert torch.allclose(lin.weight.grad, local[0] / (rank + 1) * mean_scale)
         assert torch.allclose(lin.bias.grad, local[1])                 # identical on all ranks
         assert torch.equal(lin.weight.detach(), w0)
+        _check_bucketed_averager(rank, world)
         # sharded sampling
         g = torch.Generator().manual_seed(1)
         shape = (5, 1, 4, 4)                                           # odd batch: uneven shards
