@@ -160,10 +160,13 @@ __global__ __launch_bounds__(kThreads) void bn_stats_final_kernel(const double* 
     }
 }
 
+// (the activation is a template parameter in the three kernels below: a run-time switch per element costs these
+// memory-bound loops a branch per value)
+template <int act>
 __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ w,
                                                                  const float* __restrict__ b, const float* __restrict__ res, int ldr,
-                                                                 const float* __restrict__ temb, int act, float* __restrict__ out,
+                                                                 const float* __restrict__ temb, float* __restrict__ out,
                                                                  int ldo, int64_t rows, int hw, int c) {
     const int c4n = c >> 2;
     const int64_t total = rows * c4n;
@@ -194,10 +197,11 @@ __global__ __launch_bounds__(kThreads) void bn_apply_fwd_kernel(const float* __r
 }
 
 // partial[(blk*2 + which)*C + c]: which 0 = sum dz, 1 = sum dz*xhat
+template <int act>
 __global__ __launch_bounds__(kThreads) void bn_bwd_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dout,
                                                                    int ldd, const float* __restrict__ res, int ldr,
                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                   const float* __restrict__ w, const float* __restrict__ b, int act,
+                                                                   const float* __restrict__ w, const float* __restrict__ b,
                                                                    int64_t rows, int c, double* __restrict__ partial) {
     __shared__ double sh[kThreads * 8];
     const Lanes l = lanes_for(c);
@@ -260,11 +264,12 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_final_kernel(const double* __
 
 // dx (and dresidual = dz). colsum_partial[(blk)*C + c] = sum over this block's rows of dx (the
 // gradient of the conv bias that precedes the BatchNorm: zero up to rounding).
+template <int act>
 __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dout,
                                                                  int ldd, const float* __restrict__ res, int ldr,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                  const float* __restrict__ w, const float* __restrict__ b,
-                                                                 const float* __restrict__ sums, int act, int64_t rows, int64_t stat_rows,
+                                                                 const float* __restrict__ sums, int64_t rows, int64_t stat_rows,
                                                                  int c, float* __restrict__ dx, int lddx, float* __restrict__ dres,
                                                                  int lddr, double* __restrict__ colsum_partial) {
     __shared__ double sh[kThreads * 8];
@@ -379,6 +384,20 @@ __global__ __launch_bounds__(kThreads) void colsum_final_kernel(const double* __
     out[idx] = accumulate ? out[idx] + static_cast<float>(s) : static_cast<float>(s);
 }
 
+template <typename... A>
+void launch_bwd_partial(int act, int nb, hipStream_t s, A... a) {
+    if (act == DDPM_ACT_RELU) bn_bwd_partial_kernel<DDPM_ACT_RELU><<<nb, kThreads, 0, s>>>(a...);
+    else if (act == DDPM_ACT_GELU) bn_bwd_partial_kernel<DDPM_ACT_GELU><<<nb, kThreads, 0, s>>>(a...);
+    else bn_bwd_partial_kernel<DDPM_ACT_NONE><<<nb, kThreads, 0, s>>>(a...);
+}
+
+template <typename... A>
+void launch_bwd_apply(int act, int nb, hipStream_t s, A... a) {
+    if (act == DDPM_ACT_RELU) bn_bwd_apply_kernel<DDPM_ACT_RELU><<<nb, kThreads, 0, s>>>(a...);
+    else if (act == DDPM_ACT_GELU) bn_bwd_apply_kernel<DDPM_ACT_GELU><<<nb, kThreads, 0, s>>>(a...);
+    else bn_bwd_apply_kernel<DDPM_ACT_NONE><<<nb, kThreads, 0, s>>>(a...);
+}
+
 int partial_blocks(int64_t rows, int c) {
     const int rpp = kThreads / (c / 4) > 0 ? kThreads / (c / 4) : 1;
     int64_t nb = (rows + static_cast<int64_t>(rpp) * 8 - 1) / (static_cast<int64_t>(rpp) * 8);
@@ -475,8 +494,12 @@ extern "C" int ddpm_bn_apply_fwd(const float* x, int ldx, const float* mean, con
     const int64_t rows = static_cast<int64_t>(batch) * hw;
     int64_t grid = (rows * (c / 4) + kThreads - 1) / kThreads;
     if (grid > 256 * 32) grid = 256 * 32;
-    bn_apply_fwd_kernel<<<static_cast<int>(grid), kThreads, 0, as_stream(stream)>>>(x, ldx, mean, invstd, w, b, residual, ldr, temb, act,
-                                                                                  out, ldo, rows, hw, c);
+#define DDPM_BN_LAUNCH(A) \
+    bn_apply_fwd_kernel<A><<<static_cast<int>(grid), kThreads, 0, as_stream(stream)>>>(x, ldx, mean, invstd, w, b, residual, ldr, temb, out, ldo, rows, hw, c)
+    if (act == DDPM_ACT_RELU) DDPM_BN_LAUNCH(DDPM_ACT_RELU);
+    else if (act == DDPM_ACT_GELU) DDPM_BN_LAUNCH(DDPM_ACT_GELU);
+    else DDPM_BN_LAUNCH(DDPM_ACT_NONE);
+#undef DDPM_BN_LAUNCH
     return ddpm::check_launch("bn_apply_fwd_kernel");
 }
 
@@ -494,10 +517,10 @@ extern "C" int ddpm_bn_bwd(const float* x, int ldx, const float* dout, int ldd, 
     DDPM_REQUIRE(act >= DDPM_ACT_NONE && act <= DDPM_ACT_GELU);
     hipStream_t s = as_stream(stream);
     const int nb = partial_blocks(rows, c);
-    bn_bwd_partial_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, act, rows, c, workspace);
+    launch_bwd_partial(act, nb, s, x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, rows, c, workspace);
     bn_bwd_final_kernel<<<(c + kFin - 1) / kFin, kThreads, 0, s>>>(workspace, nb, c, accumulate, dw, db, sums);
-    bn_bwd_apply_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, sums, act, rows, rows, c, dx, lddx,
-                                                dresidual, lddr, dconv_bias ? workspace : nullptr);
+    launch_bwd_apply(act, nb, s, x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, sums, rows, rows, c, dx, lddx, dresidual, lddr,
+                     dconv_bias ? workspace : nullptr);
     if (dconv_bias) colsum_final_kernel<<<dim3((c + kFin - 1) / kFin, 1), kThreads, 0, s>>>(workspace, 1, nb, c, accumulate, dconv_bias);
     return ddpm::check_launch("bn_bwd");
 }
@@ -533,7 +556,7 @@ extern "C" int ddpm_bn_bwd_sums(const float* x, int ldx, const float* dout, int 
     DDPM_REQUIRE(act >= DDPM_ACT_NONE && act <= DDPM_ACT_GELU);
     hipStream_t s = as_stream(stream);
     const int nb = partial_blocks(rows, c);
-    bn_bwd_partial_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, act, rows, c, workspace);
+    launch_bwd_partial(act, nb, s, x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, rows, c, workspace);
     pair_sums_final_kernel<<<(c + kFin - 1) / kFin, kThreads, 0, s>>>(workspace, nb, c, sums);
     return ddpm::check_launch("bn_bwd_sums");
 }
@@ -551,8 +574,8 @@ extern "C" int ddpm_bn_bwd_apply(const float* x, int ldx, const float* dout, int
     DDPM_REQUIRE(act >= DDPM_ACT_NONE && act <= DDPM_ACT_GELU);
     hipStream_t s = as_stream(stream);
     const int nb = partial_blocks(rows, c);
-    bn_bwd_apply_kernel<<<nb, kThreads, 0, s>>>(x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, sums, act, rows, total_rows, c, dx,
-                                                lddx, dresidual, lddr, dconv_bias ? workspace : nullptr);
+    launch_bwd_apply(act, nb, s, x, ldx, dout, ldd, residual, ldr, mean, invstd, w, b, sums, rows, total_rows, c, dx, lddx, dresidual, lddr,
+                     dconv_bias ? workspace : nullptr);
     if (dconv_bias) colsum_final_kernel<<<dim3((c + kFin - 1) / kFin, 1), kThreads, 0, s>>>(workspace, 1, nb, c, 0, dconv_bias);
     return ddpm::check_launch("bn_bwd_apply");
 }

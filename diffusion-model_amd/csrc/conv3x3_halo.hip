@@ -31,7 +31,7 @@ namespace conv {
 namespace {
 
 #ifndef DDPM_HALO_ABLATE
-#define DDPM_HALO_ABLATE 0   // diagnostic builds only (wrong results): bit 0 no staging in the chunk loop, bit 1 no weight loads in the loop, bit 2 no LDS fragment reads in the loop, bit 3 no master fold, bit 4 no epilogue
+#define DDPM_HALO_ABLATE 0   // diagnostic builds only (wrong results): bit 0 no staging in the chunk loop, bit 1 no weight loads in the loop, bit 2 no LDS fragment reads in the loop, bit 3 no master fold, bit 4 no epilogue, bit 5 fragment reads at tap 0 only (real data, 1/9 of the reads), bit 6 no border select on the fragment addresses
 #endif
 constexpr int kThreads = 256;
 constexpr int kPassRows = kThreads / 4;    // LDS rows staged per pass
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
                     if (dy > 0) ok = ok && down[i];
                     if (dx < 0) ok = ok && left[i];
                     if (dx > 0) ok = ok && right[i];
-                    const int addr = (dy == 0 && dx == 0) ? nat : (ok ? nat : (ZOFF | (nat & 255)));
+                    const int addr = ((DDPM_HALO_ABLATE & 64) || (dy == 0 && dx == 0)) ? nat : (ok ? nat : (ZOFF | (nat & 255)));
                     dst[i] = *reinterpret_cast<const bf16x8*>(hsm + addr + pl * 32);
                 }
             };
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
                 }
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    if (SL > 0 && !(DDPM_HALO_ABLATE & 4)) read_plane(a0, curoff, tap, 0);
+                    if (SL > 0 && !(DDPM_HALO_ABLATE & 4) && (!(DDPM_HALO_ABLATE & 32) || tap == 0)) read_plane(a0, curoff, tap, 0);
                     // weights of the next step (after tap 8: the first tap of the next chunk)
                     if (SL > 0 && !(DDPM_HALO_ABLATE & 2)) {
                         if (tap < 8) load_b(bf[(tap + 1) & 1], tap + 1, kc);
@@ -244,10 +244,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
                     if (SL > 0) {
                         const u32x4 (&b)[3] = bf[tap & 1];
                         mma(a2, b[0]);
-                        if (tap < 8 && !(DDPM_HALO_ABLATE & 4)) read_plane(a2, curoff, tap + 1, 2);
+                        if (tap < 8 && !(DDPM_HALO_ABLATE & (4 | 32))) read_plane(a2, curoff, tap + 1, 2);
                         mma(a1, b[1]);
                         mma(a1, b[0]);
-                        if (tap < 8 && !(DDPM_HALO_ABLATE & 4)) read_plane(a1, curoff, tap + 1, 1);
+                        if (tap < 8 && !(DDPM_HALO_ABLATE & (4 | 32))) read_plane(a1, curoff, tap + 1, 1);
                         mma(a0, b[2]);
                         mma(a0, b[1]);
                         mma(a0, b[0]);
@@ -292,26 +292,52 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
             const unsigned vo = static_cast<unsigned>((wm * 32 + hq) * p.ldo + n) * 4u;
             const unsigned vr = static_cast<unsigned>((wm * 32 + hq) * p.ldr + n) * 4u;
             const unsigned ldo4 = static_cast<unsigned>(p.ldo) * 4u, ldr4 = static_cast<unsigned>(p.ldr) * 4u;
+            // Every mode decision (residual, activation, time embedding) is taken once per 16 elements and each
+            // phase runs over all 16: the conditions are uniform, but a branch per element costs more than the
+            // arithmetic it guards, and a load per element would be waited for 64 times instead of four.
+            const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(p.temb ? p.temb : p.out, p.temb ? static_cast<long long>(p.batch) * p.cout * 4ll : 0ll);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i >= my_slots) continue;
+                float v[16];
 #pragma unroll
-                for (int eq = 0; eq < 4; ++eq) {
-                    const int rel0 = i * WM * 32 + 8 * eq;            // rows rel0 + (wm * 32 + hq) + 0 .. 3
-                    int bb[4] = {0, 0, 0, 0};
-                    if (p.temb) {
-                        const int4 bs = *reinterpret_cast<const int4*>(&rowb[rel0 + wm * 32 + hq]);
-                        bb[0] = bs.x; bb[1] = bs.y; bb[2] = bs.z; bb[3] = bs.w;
+                for (int e = 0; e < 16; ++e) v[e] = master[i][e] * sc + sh;
+                if (p.residual) {
+                    float rv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const unsigned rel = static_cast<unsigned>(i * WM * 32 + 8 * (e >> 2) + (e & 3));   // + wm * 32 + hq
+                        rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, vr + rel * ldr4, 0, 0));
                     }
 #pragma unroll
-                    for (int ei = 0; ei < 4; ++ei) {
-                        const unsigned rel = static_cast<unsigned>(rel0 + ei);
-                        float v = master[i][eq * 4 + ei] * sc + sh;
-                        if (p.residual) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, vr + rel * ldr4, 0, 0));
-                        v = apply_act_fast(v, p.act);
-                        if (p.temb) v += bb[ei] >= 0 ? p.temb[static_cast<unsigned>(bb[ei] * p.cout + n)] : 0.f;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, vo + rel * ldo4, 0, 0);
+                    for (int e = 0; e < 16; ++e) v[e] += rv[e];
+                }
+                if (p.act == DDPM_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                } else if (p.act == DDPM_ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = apply_act_fast(v[e], DDPM_ACT_GELU);
+                }
+                if (p.temb) {
+                    // sample of every row from the tile's table; rows past the last pixel (-1) read out of range: zero
+                    float tvv[16];
+#pragma unroll
+                    for (int eq = 0; eq < 4; ++eq) {
+                        const int4 bs = *reinterpret_cast<const int4*>(&rowb[i * WM * 32 + 8 * eq + wm * 32 + hq]);
+                        const int bb[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+                        for (int ei = 0; ei < 4; ++ei)
+                            tvv[eq * 4 + ei] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                rs_t, bb[ei] >= 0 ? static_cast<unsigned>(bb[ei] * p.cout + n) * 4u : OOB, 0, 0));
                     }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] += tvv[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned rel = static_cast<unsigned>(i * WM * 32 + 8 * (e >> 2) + (e & 3));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, vo + rel * ldo4, 0, 0);
                 }
             }
         }

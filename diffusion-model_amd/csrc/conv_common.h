@@ -123,5 +123,19 @@ static __device__ __forceinline__ void split_store(const f32x4 v, unsigned char*
 // what that kernel handles and the caller should use the generic one.
 int launch_conv3x3_halo(GemmParams& p, hipStream_t s);
 
+// 1x1 convolution with the whole packed weight matrix resident in LDS and the activations loaded straight
+// into MFMA operand registers (conv1x1_resident.hip). Same return convention as launch_conv3x3_halo.
+int launch_conv1x1_resident(GemmParams& p, hipStream_t s);
+
+// DDPM_CONV1X1_RESIDENT=0 (read once) keeps every 1x1 convolution on the generic GEMM kernel: a diagnostic
+// switch for A/B measurements.
+inline bool resident_1x1() {
+    static const bool on = [] {
+        const char* e = getenv("DDPM_CONV1X1_RESIDENT");
+        return !(e && strcmp(e, "0") == 0);
+    }();
+    return on;
+}
+
 }  // namespace conv
 }  // namespace ddpm

@@ -560,20 +560,42 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
                 const float sh = p.shift ? p.shift[n] : 0.0f;
                 const unsigned vo = static_cast<unsigned>((wm * 32 + 4 * h) * p.ldo + n) * 4u;
                 const unsigned vr = static_cast<unsigned>((wm * 32 + 4 * h) * p.ldr + n) * 4u;
+                // mode decisions once per 16 elements, each phase over all 16 (a branch or a waited-for load per
+                // element costs more than the arithmetic)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     if (i >= my_slots) continue;
+                    float v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = master[i][j][e] * sc + sh;
+                    if (p.residual) {
+                        float rv[16];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const unsigned rel = static_cast<unsigned>(i * 64 + (e & 3) + 8 * (e >> 2));   // + wm * 32 + 4 * h
+                            rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, vr + rel * ldr4, 0, 0));
+                        }
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] += rv[e];
+                    }
+                    if (p.act == DDPM_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    } else if (p.act == DDPM_ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = apply_act_fast(v[e], DDPM_ACT_GELU);
+                    }
+                    if (p.temb) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int4 info = rowinfo[i * 64 + (e & 3) + 8 * (e >> 2) + wm * 32 + 4 * h];
+                            v[e] += info.x >= 0 ? p.temb[static_cast<int64_t>(info.y) * p.cout + n] : 0.f;
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const unsigned rel = static_cast<unsigned>(i * 64 + (e & 3) + 8 * (e >> 2));   // + wm * 32 + 4 * h
-                        float v = master[i][j][e] * sc + sh;
-                        if (p.residual) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, vr + rel * ldr4, 0, 0));
-                        v = apply_act_fast(v, p.act);
-                        if (p.temb) {
-                            const int4 info = rowinfo[rel + wm * 32 + 4 * h];
-                            v += info.x >= 0 ? p.temb[static_cast<int64_t>(info.y) * p.cout + n] : 0.f;
-                        }
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, vo + rel * ldo4, 0, 0);
+                        const unsigned rel = static_cast<unsigned>(i * 64 + (e & 3) + 8 * (e >> 2));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, vo + rel * ldo4, 0, 0);
                     }
                 }
             }
@@ -955,6 +977,10 @@ extern "C" int ddpm_conv1x1_fwd(const ddpm_conv_desc* d, const float* src1, cons
     GemmParams p;
     fill_common(p, d, src1, src2, w_packed, ep, out);
     p.taps = 1;
+    if (split_math() && resident_1x1()) {
+        const int rc = launch_conv1x1_resident(p, as_stream(stream));
+        if (rc <= 0) return rc;   // launched, or failed; positive = shape for the generic kernel
+    }
     return launch_gemm<MODE_CONV1>(p, as_stream(stream));
 }
 

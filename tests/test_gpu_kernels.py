@@ -198,6 +198,44 @@ def test_conv1x1(case):
     assert_close(from_nhwc(out), F.conv2d(x, w[:, :, None, None], b), TOL, f"conv1x1 {case}")
 
 
+@pytest.mark.parametrize("case", [(32, 784, 128, 160, 0), (24, 1024, 64, 80, 0), (21, 784, 160, 128, 1), (17, 1024, 80, 64, 1), (40, 441, 128, 72, 2),
+                                  (33, 500, 68, 192, 0), (20, 900, 128, 33, 2)])
+def test_conv1x1_many_rows(case):
+    """Shapes of the attention projections at full resolution (rows >= 16384, weights small enough to stay in LDS): the
+    kernel with resident weights. mode 0: bias; 1: the data-gradient form (no bias, residual add, strided residual);
+    2: scale/shift + GELU. Ragged row counts, columns that do not fill their last 32-block, K that is not a multiple of 16."""
+    B, N, ci, co, mode = case
+    x, w = rnd((B, ci, N, 1), 1), rnd((co, ci), 2, ci ** -0.5)
+    b, sc = rnd((co,), 3), rnd((co,), 4).abs() + 0.5
+    res = rnd((B, co, N, 1), 5)
+    out = torch.full((B, N, 1, co + 4), 7.0, device="cuda")
+    wd = torch.empty(packed_floats(1, co, ci), device="cuda")
+    call("ddpm_pack_conv1x1", P(w.cuda()), co, ci, 0, P(wd), stream())
+    resd = torch.zeros((B, N, 1, co + 8), device="cuda")
+    resd[..., :co] = to_nhwc(res)
+    d = ConvDesc(batch=B, in_h=N, in_w=1, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co + 4, act=2 if mode == 2 else 0, ldr=co + 8, out_h=N, out_w=1)
+    keep = [b.cuda(), sc.cuda()]
+    ep = {0: Epilogue(None, P(keep[0]), None, None), 1: Epilogue(None, None, P(resd), None), 2: Epilogue(P(keep[1]), P(keep[0]), None, None)}[mode]
+    call("ddpm_conv1x1_fwd", C.byref(d), P(to_nhwc(x)), None, P(wd), C.byref(ep), P(out), stream())
+    want = F.conv2d(x, w[:, :, None, None])
+    want = {0: want + b[None, :, None, None], 1: want + res, 2: F.gelu(want * sc[None, :, None, None] + b[None, :, None, None])}[mode]
+    assert_close(from_nhwc(out[..., :co]), want, TOL, f"conv1x1 many rows {case}")
+    assert torch.all(out[..., co:] == 7.0)
+    # the same rows in pieces of fewer than 16384 rows take the generic GEMM kernel: identical bits, so that a result does
+    # not depend on how a batch was cut
+    xd = to_nhwc(x)
+    pieces = []
+    for b0 in range(0, B, 8):
+        nb = min(8, B - b0)
+        o = torch.full((nb, N, 1, co + 4), 7.0, device="cuda")
+        d2 = ConvDesc(batch=nb, in_h=N, in_w=1, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co + 4, act=d.act, ldr=co + 8, out_h=N, out_w=1)
+        rp = resd[b0:b0 + nb]
+        ep2 = {0: Epilogue(None, P(keep[0]), None, None), 1: Epilogue(None, None, P(rp), None), 2: Epilogue(P(keep[1]), P(keep[0]), None, None)}[mode]
+        call("ddpm_conv1x1_fwd", C.byref(d2), P(xd[b0:b0 + nb]), None, P(wd), C.byref(ep2), P(o), stream())
+        pieces.append(o)
+    assert torch.equal(torch.cat(pieces), out)
+
+
 @pytest.mark.parametrize("case", [(2, 7, 7, 64, 32, 14, 14), (2, 7, 7, 32, 16, 15, 15), (2, 16, 16, 32, 16, 16, 16),
                                   (1, 14, 14, 128, 64, 28, 28), (3, 15, 15, 8, 4, 15, 15), (2, 7, 5, 16, 8, 17, 9)])
 def test_convT2x2_pad_crop(case):

@@ -72,8 +72,8 @@ def main():
         call("ddpm_pack_conv1x1", P(w), co, ci, 0, P(wp), S())
         y = torch.empty(B, H, W, co, device=dev)
         d = ConvDesc(batch=B, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=0, ldr=0, out_h=H, out_w=W)
-        sc, sh = torch.ones(co, device=dev), torch.zeros(co, device=dev)
-        ep = Epilogue(P(sc), P(sh), None, None)
+        sh = torch.zeros(co, device=dev)
+        ep = Epilogue(None, P(sh), None, None)
         t = timeit(lambda: call("ddpm_conv1x1_fwd", C.byref(d), P(x), None, P(wp), C.byref(ep), P(y), S()), iters)
         gb = 4.0 * B * H * W * (ci + co)
         print(f"conv1x1 B={B} {H}x{W} {ci}->{co}: {t*1e6:.1f} us  {2.0*B*H*W*ci*co/t/1e12:.1f} TFLOP/s  {gb/t/1e12:.2f} TB/s algorithmic")
