@@ -250,11 +250,15 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst, 
     *reinterpret_cast<u32x2*>(dst + 2 * plane_stride) = lo;
 }
 
-template <int DQ>
+// QB = 32-query blocks per wave, NCT = 32-channel blocks per workgroup. Per 32 x 32 tile of scores a wave spends
+// about 1050 cycles of VALU on the softmax and the split of the probabilities, 192 * KC cycles of MFMA on the scores
+// and 384 * NCT cycles of MFMA on the value product: with 64 channels (NCT = 2) the two are level, and every further
+// 64-channel slice handled by ANOTHER workgroup repeats the scores and the softmax. Tensors of 128 channels and more
+// therefore run (QB, NCT) = (1, 4): 32 queries x 128 channels per wave, which makes the matrix pipe the longer side
+// and halves the repeated work; 64-channel tensors keep (2, 2).
+template <int DQ, int QB, int NCT>
 __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnParams p) {
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
-    constexpr int QB = 2;                       // 32-query blocks per wave
-    constexpr int NCT = 2;                      // 32-channel blocks per workgroup
     constexpr int CS = 32 * NCT;
     constexpr int KD = DQ < 16 ? 16 : DQ;       // K/Q depth padded to the MFMA's 16
     constexpr int KC = KD / 16;                 // depth chunks
@@ -502,12 +506,29 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
     }
 }
 
+// DDPM_ATTN_WIDE=0 (read once) keeps tensors of 128 channels and more on the 64-channel configuration: a diagnostic
+// switch for A/B measurements.
+inline bool wide_attention() {
+    static const bool on = [] {
+        const char* e = getenv("DDPM_ATTN_WIDE");
+        return !(e && strcmp(e, "0") == 0);
+    }();
+    return on;
+}
+
 template <int DQ>
 int launch_dq(const AttnParams& p, int batch, hipStream_t s) {
-    if (ddpm::split_math() && p.n >= 128 && p.c >= 64) {
-        const dim3 g((p.n + 255) / 256, (p.c + 63) / 64, batch);
-        attention_fwd_x3_kernel<DQ><<<g, 256, 0, s>>>(p);
+    if constexpr (DQ <= 64) {   // 128 query channels (C = 1024): only the bottleneck has them, its maps are short
+      if (ddpm::split_math() && p.n >= 128 && p.c >= 64) {
+        if (p.c >= 128 && wide_attention()) {
+            const dim3 g((p.n + 127) / 128, (p.c + 127) / 128, batch);
+            attention_fwd_x3_kernel<DQ, 1, 4><<<g, 256, 0, s>>>(p);
+        } else {
+            const dim3 g((p.n + 255) / 256, (p.c + 63) / 64, batch);
+            attention_fwd_x3_kernel<DQ, 2, 2><<<g, 256, 0, s>>>(p);
+        }
         return ddpm::check_launch("attention_fwd_x3_kernel");
+      }
     }
     const int q_blocks = (p.n + 127) / 128;
     if (p.c > 64) {
@@ -531,7 +552,7 @@ extern "C" int ddpm_attention_fwd(const float* qkv, const float* x, int ldx, con
                                   void* stream) {
     DDPM_REQUIRE(qkv && x && gamma && out && batch > 0 && batch <= 65535 && n > 0 && c > 0);
     DDPM_REQUIRE((c & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && ldx >= c && ldo >= c);
-    DDPM_REQUIRE(dq == 8 || dq == 16 || dq == 32 || dq == 64);
+    DDPM_REQUIRE(dq == 8 || dq == 16 || dq == 32 || dq == 64 || dq == 128);
     DDPM_REQUIRE(ddpm::aligned16(qkv) && ddpm::aligned16(x) && ddpm::aligned16(out));
     DDPM_REQUIRE(!attn_raw || ddpm::aligned16(attn_raw));
     AttnParams p;
@@ -555,6 +576,7 @@ extern "C" int ddpm_attention_fwd(const float* qkv, const float* x, int ldx, con
         case 8: return launch_dq<8>(p, batch, s);
         case 16: return launch_dq<16>(p, batch, s);
         case 32: return launch_dq<32>(p, batch, s);
-        default: return launch_dq<64>(p, batch, s);
+        case 64: return launch_dq<64>(p, batch, s);
+        default: return launch_dq<128>(p, batch, s);
     }
 }

@@ -1189,7 +1189,7 @@ extern "C" int ddpm_attention_bwd(const float* qkv, const float* dy, int ldd, co
                                   void* stream) {
     DDPM_REQUIRE(qkv && dy && attn_raw && lse && gamma && workspace && e_scratch && dqkv && dgamma);
     DDPM_REQUIRE(batch > 0 && batch <= 65535 && n > 0 && c > 0 && (c & 3) == 0 && c <= 1024 && (ldd & 3) == 0 && ldd >= c);
-    DDPM_REQUIRE(dq == 8 || dq == 16 || dq == 32 || dq == 64);
+    DDPM_REQUIRE(dq == 8 || dq == 16 || dq == 32 || dq == 64 || dq == 128);
     DDPM_REQUIRE(ddpm::aligned16(qkv) && ddpm::aligned16(dy) && ddpm::aligned16(attn_raw) && ddpm::aligned16(dqkv));
     hipStream_t s = ddpm::as_stream(stream);
     const int64_t rows = static_cast<int64_t>(batch) * n;
@@ -1219,6 +1219,7 @@ extern "C" int ddpm_attention_bwd(const float* qkv, const float* dy, int ldd, co
         case 8: return launch_bwd<8>(p, batch, s);
         case 16: return launch_bwd<16>(p, batch, s);
         case 32: return launch_bwd<32>(p, batch, s);
-        default: return launch_bwd<64>(p, batch, s);
+        case 64: return launch_bwd<64>(p, batch, s);
+        default: return launch_bwd<128>(p, batch, s);
     }
 }

@@ -72,6 +72,9 @@ class UNetEngine(TrainMixin):
     def __init__(self, module, variant, in_channels, out_channels, base_channels, embedding_dim, num_classes):
         if base_channels % 4 != 0:
             raise NotImplementedError("base_channels must be a multiple of 4 for the 16-byte vector paths")
+        if base_channels > 128:
+            raise NotImplementedError("base_channels above 128 is not supported (the BatchNorm reductions take at most 1024 channels "
+                                      "and the attention blocks at most 128 query channels)")
         if embedding_dim % 2 != 0 or embedding_dim < 4:
             raise NotImplementedError("embedding_dim must be even and >= 4")
         self.m = module
@@ -353,8 +356,8 @@ class UNetEngine(TrainMixin):
         b, h, w = x.bhw
         c = x.c
         wq, bq, dqp, _ = self.packed_qkv(key)
-        if dqp not in (8, 16, 32, 64):
-            raise NotImplementedError(f"attention with C/8 = {c // 8} query channels is not supported")
+        if dqp not in (8, 16, 32, 64, 128):
+            raise NotImplementedError(f"attention with C/8 = {c // 8} query channels is not supported (at most 128: base_channels 128)")
         qkv = View(self._new(b, h, w, 2 * dqp + c, x.buf))
         self.conv1x1(x, wq, bq, 2 * dqp + c, qkv)
         raw = lse = None

@@ -318,7 +318,10 @@ class TrainMixin:
             self._launch(self._wgrad_label("conv1x1", lq, c), 2.0 * b * n * lq * c, "ddpm_conv1x1_wgrad", dqkv.ptr, lq, lq, x.ptr, x.ld, c, b * n,
                          _ptr(gw), _stream())
         gb = self._gnew(lq, dev)
-        call("ddpm_colsum", dqkv.ptr, lq, 1, b * n, lq, _ptr(ws), 0, _ptr(gb), _stream())
+        for c0 in range(0, lq, 1024):                        # the column-sum kernel takes at most 1024 columns a call
+            cw = min(1024, lq - c0)
+            call("ddpm_colsum", C.c_void_p(dqkv.buf.data_ptr() + 4 * c0), lq, 1, b * n, cw, _ptr(ws), 0, C.c_void_p(gb.data_ptr() + 4 * c0),
+                 _stream())
         self._gflush()
         for name, lo, cnt in (("query", 0, dq), ("key", dqp, dq), ("value", 2 * dqp, c)):
             grads[f"{key}.{name}.weight"] = gw[lo:lo + cnt].reshape(self.T(f"{key}.{name}.weight").shape)

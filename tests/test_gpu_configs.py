@@ -75,6 +75,37 @@ def test_colour_64x64_full_width_eval():
         assert_close(fm.cpu(), fms[i], 5e-5, f"64x64 full-width eval fm{i}")
 
 
+@pytest.mark.parametrize("hw", [32, 28])
+def test_base_channels_128_eval_and_gradients(hw):
+    """The wide colour model the reference's CIFAR scripts build (UNet(3, 3, 128, 128), second-iteration/main.py:45):
+    1024 channels and 128 query channels in the bottleneck, a fused q|k|v projection of 1280 columns."""
+    m = build(2, 3, 128, 128, 14)
+    sd = cpu_sd(m)
+    x, tgt = seeded_tensor((2, 3, hw, hw), 41, "x"), seeded_tensor((2, 3, hw, hw), 141, "tgt")
+    t = torch.tensor([650, 3])
+    m.eval()
+    with torch.no_grad():
+        out = m(x.cuda(), t.cuda())
+        want, fms, _ = O.unet_forward(sd, 2, x, t, None, train=False)
+    assert_close(out.cpu(), want, 5e-5, "base-128 eval eps")
+    for i, fm in enumerate(m.feature_maps):
+        assert_close(fm.cpu(), fms[i], 5e-5, f"base-128 eval fm{i}")
+    m.train()
+    loss = torch.nn.MSELoss()(m(x.cuda(), t.cuda()), tgt.cuda())
+    loss.backward()
+    ref_loss, grads, _, _ = O.loss_and_grads(sd, 2, x, t, tgt)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * ref_loss.item()
+    worst = []
+    for k, p in m.named_parameters():
+        ref = grads[k]
+        err = (p.grad.cpu() - ref).abs().max().item()
+        worst.append((err / (2e-3 * ref.abs().max().item() + 5e-6), k, err))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 1.0, worst[:6]
+    with pytest.raises(NotImplementedError, match="above 128"):
+        pkg.make_unet_class(2)(3, 3, 160, 128)
+
+
 def test_colour_32x32_full_width_train_step():
     """(3,3,64,128) on 3x32x32: loss and every parameter gradient of one eps-MSE step.
 
