@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restr
                                                              const float* __restrict__ residual_unused, const float* __restrict__ temb,
                                                              int act, float* __restrict__ out, int batch, int cin, int h, int wd,
                                                              int cout, int ldo) {
-    __shared__ __attribute__((aligned(16))) float sw[kMaxLdsFloats];
+    extern __shared__ __attribute__((aligned(16))) float sw[];   // cin * 9 * cout floats
     const int kt = cin * 9;
     for (int i = threadIdx.x; i < kt * cout; i += blockDim.x) {
         const int co = i % cout, k = i / cout;  // k = ci*9 + tap
@@ -62,99 +62,161 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restr
     }
 }
 
-// 16 lanes per pixel, each holding 4 channels of a 64-channel slab; weights in LDS as [cout][c].
-__global__ __launch_bounds__(256) void conv1x1_final_kernel(const float* __restrict__ x, int ld, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ out, int batch,
-                                                             int hw, int c, int cout) {
-    __shared__ __attribute__((aligned(16))) float sw[kMaxLdsFloats];
-    for (int i = threadIdx.x; i < c * cout; i += blockDim.x) sw[i] = w[i];
-    __syncthreads();
-    const int sub = threadIdx.x & 15;
-    const int64_t npix = static_cast<int64_t>(batch) * hw;
-    const int64_t groups = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 4);
-    // every lane of a wave iterates the same number of times (shuffles need all 16 lanes of a group)
-    const int64_t iters = (npix + groups - 1) / groups;
-    for (int64_t it = 0; it < iters; ++it) {
-        const int64_t pix = it * groups + static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 4) + (threadIdx.x >> 4);
-        const bool live = pix < npix;
-        for (int co = 0; co < cout; ++co) {
-            float acc = 0.f;
-            if (live) {
-                for (int c0 = sub * 4; c0 < c; c0 += 64) {
-                    const float4 v = *reinterpret_cast<const float4*>(x + pix * ld + c0);
-                    const float4 wv = *reinterpret_cast<const float4*>(sw + co * c + c0);
-                    acc += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
-                }
-            }
-            acc += __shfl_xor(acc, 8);
-            acc += __shfl_xor(acc, 4);
-            acc += __shfl_xor(acc, 2);
-            acc += __shfl_xor(acc, 1);
-            if (live && sub == 0) {
-                const int64_t b = pix / hw, q = pix % hw;
-                out[(b * cout + co) * hw + q] = acc + (bias ? bias[co] : 0.f);
-            }
-        }
-    }
-}
-
-// The final 1x1 conv and the reverse ancestral step in one pass: eps-hat never goes to memory. Same thread
-// layout and the same summation order as conv1x1_final_kernel (so eps-hat has the same bits), followed by
-// the reverse-step expression on the lane that holds the pixel's sum. Noise: an injected tensor (NOISE = 1),
-// drawn in place from the Philox stream (NOISE = 2), or none (NOISE = 0: the t == 0 step).
+// The final 1x1 conv (NHWC features -> NCHW, 1 or 3 channels) with or without the reverse ancestral step fused
+// behind it. 16 lanes share a pixel, each holding 4 channels of every 64-channel slab; weights sit in LDS as
+// [cout][c]; the 16 partial sums are combined inside the VALU (row16_sum) and lane 0 of the group finishes the pixel.
+// MODE 0: out = eps-hat. MODE 1..3: eps-hat never goes to memory -- the reverse-step expression is applied on the
+// spot (1: no noise term, the t == 0 step; 2: noise read from a tensor; 3: noise drawn in place from the Philox
+// stream). Every mode forms eps-hat with the same operations in the same order, so its bits do not depend on the mode.
+// The kernel is memory-bound on the feature read (256 B per pixel at 64 channels): a group works on PX pixels at a
+// time, all of their feature loads issued (non-temporal: the features are dead after this kernel) before the first sum.
 struct FinalStepArgs {
     const float* feat;       // [B][hw][ld] NHWC features
     const float* w;          // [cout][c]
     const float* bias;       // [cout] or null
     const float* x_t;        // [B][cout][hw] NCHW
-    const float* z;          // NCHW noise (NOISE == 1)
+    const float* z;          // NCHW noise (MODE 2)
     const float* eps_cond;   // NCHW conditional eps-hat: this pass is the unconditional one of a guided step (or null)
-    float* x_out;            // NCHW
+    float* x_out;            // NCHW: eps-hat (MODE 0) or x_{t-1}
     float* eps_out;          // optional NCHW copy of this pass's eps-hat (or null)
     float c1, c2, c3, cfg_w;
     uint64_t seed, call;
     int ld, batch, hw, c, cout;
 };
 
-template <int NOISE>
-__global__ __launch_bounds__(256) void final_step_kernel(const FinalStepArgs a) {
-    __shared__ __attribute__((aligned(16))) float sw[kMaxLdsFloats];
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
+// Sum over the 16 lanes of a DPP row (every lane gets the total): data-parallel-primitive moves inside the VALU,
+// no trip through the LDS crossbar that a shuffle takes. Lane pairs, then quads, then the two halves of 8, then 16.
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp = [](float x, int ctrl_tag) -> float {
+        const int b = __builtin_bit_cast(int, x);
+        int r;
+        if (ctrl_tag == 0) r = __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
+        else if (ctrl_tag == 1) r = __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+        else if (ctrl_tag == 2) r = __builtin_amdgcn_update_dpp(0, b, 0x141, 0xf, 0xf, true);  // row_half_mirror
+        else r = __builtin_amdgcn_update_dpp(0, b, 0x140, 0xf, 0xf, true);                     // row_mirror
+        return __builtin_bit_cast(float, r);
+    };
+    v += dpp(v, 0);
+    v += dpp(v, 1);
+    v += dpp(v, 2);
+    v += dpp(v, 3);
+    return v;
+}
+
+template <int MODE>
+__device__ __forceinline__ void final_finish(const FinalStepArgs& a, int64_t pix, int co, float acc, bool low) {
+    const int64_t b = pix / a.hw, q = pix % a.hw;
+    const int64_t e = (b * a.cout + co) * a.hw + q;
+    float eps = acc + (a.bias ? a.bias[co] : 0.f);
+    if (MODE == 0) {
+        a.x_out[e] = eps;
+        return;
+    }
+    if (a.eps_out) a.eps_out[e] = eps;
+    if (a.eps_cond) eps = ddpm::guided_eps(a.eps_cond[e], eps, a.cfg_w, low);
+    float zv = 0.f;
+    if (MODE == 2) zv = a.z[e];
+    if (MODE == 3) zv = ddpm::philox_normal(a.seed, a.call, static_cast<uint64_t>(e));
+    a.x_out[e] = ddpm::step1(a.x_t[e], eps, zv, a.c1, a.c2, a.c3, MODE != 1);
+}
+
+// CI = 64-channel slabs per pixel known at compile time (1 or 2: PX pixels in flight), 0 = any width (one pixel)
+template <int MODE, int CI>
+__global__ __launch_bounds__(256) void final_conv_kernel(const FinalStepArgs a) {
+    // (dynamic: c * cout floats. A fixed 48 KiB array would cap the kernel at three workgroups per CU, too few
+    // loads in flight for a kernel that does nothing but stream the features)
+    extern __shared__ __attribute__((aligned(16))) float sw[];
     for (int i = threadIdx.x; i < a.c * a.cout; i += blockDim.x) sw[i] = a.w[i];
     __syncthreads();
+    constexpr int PX = CI == 0 ? 1 : 4;
     const int sub = threadIdx.x & 15;
     const int64_t npix = static_cast<int64_t>(a.batch) * a.hw;
     const int64_t groups = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 4);
-    const int64_t iters = (npix + groups - 1) / groups;
+    // every lane of a wave iterates the same number of times (the row sums need all 16 lanes of a group)
+    const int64_t iters = (npix + groups * PX - 1) / (groups * PX);
     const bool low = fabsf(a.cfg_w) < 0.5f;
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 4) + (threadIdx.x >> 4);
     for (int64_t it = 0; it < iters; ++it) {
-        const int64_t pix = it * groups + static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 4) + (threadIdx.x >> 4);
-        const bool live = pix < npix;
-        for (int co = 0; co < a.cout; ++co) {
-            float acc = 0.f;
-            if (live) {
-                for (int c0 = sub * 4; c0 < a.c; c0 += 64) {
-                    const float4 v = *reinterpret_cast<const float4*>(a.feat + pix * a.ld + c0);
-                    const float4 wv = *reinterpret_cast<const float4*>(sw + co * a.c + c0);
-                    acc += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+        int64_t pix[PX];
+        bool live[PX];
+        vf4 v[PX][CI == 0 ? 1 : CI];
+#pragma unroll
+        for (int u = 0; u < PX; ++u) {
+            pix[u] = (it * PX + u) * groups + gid;
+            live[u] = pix[u] < npix;
+            if (CI > 0) {
+#pragma unroll
+                for (int k = 0; k < (CI == 0 ? 1 : CI); ++k) {
+                    v[u][k] = vf4{0.f, 0.f, 0.f, 0.f};
+                    if (live[u]) v[u][k] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(a.feat + pix[u] * a.ld + k * 64 + sub * 4));
                 }
             }
-            acc += __shfl_xor(acc, 8);
-            acc += __shfl_xor(acc, 4);
-            acc += __shfl_xor(acc, 2);
-            acc += __shfl_xor(acc, 1);
-            if (live && sub == 0) {
-                const int64_t b = pix / a.hw, q = pix % a.hw;
-                const int64_t e = (b * a.cout + co) * a.hw + q;
-                float eps = acc + (a.bias ? a.bias[co] : 0.f);
-                if (a.eps_out) a.eps_out[e] = eps;
-                if (a.eps_cond) eps = ddpm::guided_eps(a.eps_cond[e], eps, a.cfg_w, low);
-                float zv = 0.f;
-                if (NOISE == 1) zv = a.z[e];
-                if (NOISE == 2) zv = ddpm::philox_normal(a.seed, a.call, static_cast<uint64_t>(e));
-                a.x_out[e] = ddpm::step1(a.x_t[e], eps, zv, a.c1, a.c2, a.c3, NOISE != 0);
+        }
+        auto dot = [&](int u, int co) -> float {
+            float acc = 0.f;
+            if (CI > 0) {
+#pragma unroll
+                for (int k = 0; k < (CI == 0 ? 1 : CI); ++k) {
+                    const float4 wv = *reinterpret_cast<const float4*>(sw + co * a.c + k * 64 + sub * 4);
+                    acc += v[u][k].x * wv.x + v[u][k].y * wv.y + v[u][k].z * wv.z + v[u][k].w * wv.w;
+                }
+            } else if (live[u]) {
+                for (int c0 = sub * 4; c0 < a.c; c0 += 64) {
+                    const float4 xv = *reinterpret_cast<const float4*>(a.feat + pix[u] * a.ld + c0);
+                    const float4 wv = *reinterpret_cast<const float4*>(sw + co * a.c + c0);
+                    acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+                }
+            }
+            return row16_sum(acc);       // every lane of the group holds the pixel's sum
+        };
+        if (a.cout <= 4) {
+            // up to PX * 4 <= 16 (pixel, channel) results per group: lane `sub` finishes result number `sub`, so the
+            // loads, the noise draw and the store of the step run on as many lanes side by side instead of one after
+            // the other on lane 0
+            float mine = 0.f;
+            int64_t my_pix = 0;
+            bool my_live = false;
+            const int my_co = sub % a.cout;
+#pragma unroll
+            for (int u = 0; u < PX; ++u) {
+#pragma unroll
+                for (int co = 0; co < 4; ++co) {
+                    if (co < a.cout) {
+                        const float tot = dot(u, co);
+                        if (sub == u * a.cout + co) {
+                            mine = tot;
+                            my_pix = pix[u];
+                            my_live = live[u];
+                        }
+                    }
+                }
+            }
+            if (my_live && sub < PX * a.cout) final_finish<MODE>(a, my_pix, my_co, mine, low);
+        } else {
+            for (int co = 0; co < a.cout; ++co) {
+#pragma unroll
+                for (int u = 0; u < PX; ++u) {
+                    const float tot = dot(u, co);
+                    if (live[u] && sub == 0) final_finish<MODE>(a, pix[u], co, tot, low);
+                }
             }
         }
     }
+}
+
+template <int MODE>
+int launch_final(const FinalStepArgs& a, hipStream_t s) {
+    const int64_t npix = static_cast<int64_t>(a.batch) * a.hw;
+    const int px = (a.c == 64 || a.c == 128) ? 4 : 1;
+    int64_t grid = (npix + 16 * px - 1) / (16 * px);
+    if (grid > 256 * 32) grid = 256 * 32;
+    const size_t lds = sizeof(float) * a.c * a.cout;
+    if (a.c == 64) final_conv_kernel<MODE, 1><<<static_cast<int>(grid), 256, lds, s>>>(a);
+    else if (a.c == 128) final_conv_kernel<MODE, 2><<<static_cast<int>(grid), 256, lds, s>>>(a);
+    else final_conv_kernel<MODE, 0><<<static_cast<int>(grid), 256, lds, s>>>(a);
+    return ddpm::check_launch("final_conv_kernel");
 }
 
 }  // namespace
@@ -171,14 +233,10 @@ extern "C" int ddpm_final_conv_reverse_step(const float* feat, int ld, const flo
     a.feat = feat; a.w = w; a.bias = bias; a.x_t = x_t; a.z = z; a.eps_cond = eps_cond; a.x_out = x_out; a.eps_out = eps_out;
     a.c1 = c1; a.c2 = c2; a.c3 = c3; a.cfg_w = cfg_w; a.seed = seed; a.call = call;
     a.ld = ld; a.batch = batch; a.hw = h * w_; a.c = c; a.cout = cout;
-    const int64_t npix = static_cast<int64_t>(batch) * h * w_;
-    int64_t grid = (npix + 15) / 16;
-    if (grid > 256 * 16) grid = 256 * 16;
     hipStream_t s = as_stream(stream);
-    if (noise_mode == 0) final_step_kernel<0><<<static_cast<int>(grid), 256, 0, s>>>(a);
-    else if (noise_mode == 1) final_step_kernel<1><<<static_cast<int>(grid), 256, 0, s>>>(a);
-    else final_step_kernel<2><<<static_cast<int>(grid), 256, 0, s>>>(a);
-    return ddpm::check_launch("final_step_kernel");
+    if (noise_mode == 0) return launch_final<1>(a, s);
+    if (noise_mode == 1) return launch_final<2>(a, s);
+    return launch_final<3>(a, s);
 }
 
 extern "C" int ddpm_conv3x3_first_fwd(const float* x_nchw, const float* w, const ddpm_epilogue* ep, int act, float* out, int batch,
@@ -191,7 +249,7 @@ extern "C" int ddpm_conv3x3_first_fwd(const float* x_nchw, const float* w, const
     const int64_t total = static_cast<int64_t>(batch) * h * w_ * (cout / 4);
     int64_t grid = (total + 255) / 256;
     if (grid > 256 * 16) grid = 256 * 16;
-    conv3x3_first_kernel<<<static_cast<int>(grid), 256, 0, as_stream(stream)>>>(x_nchw, w, ep->scale, ep->shift, nullptr, ep->temb,
+    conv3x3_first_kernel<<<static_cast<int>(grid), 256, sizeof(float) * cin * 9 * cout, as_stream(stream)>>>(x_nchw, w, ep->scale, ep->shift, nullptr, ep->temb,
                                                                                act, out, batch, cin, h, w_, cout, ldo);
     return ddpm::check_launch("conv3x3_first_kernel");
 }
@@ -201,9 +259,8 @@ extern "C" int ddpm_conv1x1_final_fwd(const float* x, int ld, const float* w, co
     DDPM_REQUIRE(x && w && out_nchw && batch > 0 && h > 0 && w_ > 0 && c > 0 && cout > 0);
     DDPM_REQUIRE((c & 3) == 0 && (ld & 3) == 0 && ld >= c && ddpm::aligned16(x));
     DDPM_REQUIRE(c * cout <= kMaxLdsFloats);
-    const int64_t npix = static_cast<int64_t>(batch) * h * w_;
-    int64_t grid = (npix + 15) / 16;
-    if (grid > 256 * 16) grid = 256 * 16;
-    conv1x1_final_kernel<<<static_cast<int>(grid), 256, 0, as_stream(stream)>>>(x, ld, w, bias, out_nchw, batch, h * w_, c, cout);
-    return ddpm::check_launch("conv1x1_final_kernel");
+    FinalStepArgs a = {};
+    a.feat = x; a.w = w; a.bias = bias; a.x_out = out_nchw;
+    a.ld = ld; a.batch = batch; a.hw = h * w_; a.c = c; a.cout = cout;
+    return launch_final<0>(a, as_stream(stream));
 }

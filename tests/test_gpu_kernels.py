@@ -31,7 +31,7 @@ def test_reverse_step_bit_exact_golden(tag):
         assert out.cpu().numpy().tobytes() == g[f"{tag}_step_t{tt}"].tobytes()
 
 
-@pytest.mark.parametrize("n", [1, 3, 4, 1023, 4096 * 3 + 2, 1 << 22])
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 4096 * 3 + 2, 1 << 22, (1 << 23) + 4096 * 5 + 3])   # the last: streaming variant
 @pytest.mark.parametrize("w", [0.0, 0.25, 0.5, 2.0])
 def test_reverse_step_ragged_and_guided(n, w):
     x, e, u, z = (rnd((n,), s) for s in (1, 2, 3, 4))
