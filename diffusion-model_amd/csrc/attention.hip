@@ -13,6 +13,8 @@
 //                   never leave the register file. The output tile again has lane = query, so the
 //                   online-softmax rescale is a per-lane multiply.
 #include "attention_small.h"
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -75,24 +77,21 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) 
     float m_run = -INFINITY, l_run = 0.f;
 
     f32x4 kreg[KPT], vreg[VPT];
+    // K and V rows come through a range-checked descriptor over the sample's [n][lq] block: rows past the last key
+    // and channels past the last one read as zero without a branch
+    const __amdgpu_buffer_rsrc_t rs_kv = ddpm::buffer_over(base, static_cast<long long>(p.n) * p.lq * 4ll);
     auto load_tile = [&](int j0) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (DQ / 4), c4 = f % (DQ / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (f < KF4 && j0 + row < p.n)
-                v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(j0 + row) * p.lq + p.dqp + c4 * 4);
-            kreg[i] = v;
+            kreg[i] = ddpm::buffer_load4(rs_kv, f < KF4 ? static_cast<unsigned>((j0 + row) * p.lq + p.dqp + c4 * 4) * 4u : ddpm::kOob);
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CS / 4), c4 = f % (CS / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (j0 + row < p.n && cbase + c4 * 4 < p.c)
-                v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(j0 + row) * p.lq + 2 * p.dqp + cbase + c4 * 4);
-            vreg[i] = v;
+            vreg[i] = ddpm::buffer_load4(rs_kv, cbase + c4 * 4 < p.c ? static_cast<unsigned>((j0 + row) * p.lq + 2 * p.dqp + cbase + c4 * 4) * 4u : ddpm::kOob);
         }
     };
     auto store_tile = [&](int buf) {
@@ -209,42 +208,41 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Two floats -> one 32-bit word of each bf16 plane (element 0 in the low half-word). x = hi + mid + lo exactly: two
+// truncations to the upper 16 bits, each followed by an exact subtraction. (Scalar subtractions on purpose: the packed
+// v_pk_add_f32 form measured 2 % slower in the kernels below.)
+__device__ __forceinline__ void split2(const float v0, const float v1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
+    const float r0 = v0 - __uint_as_float(u0 & 0xffff0000u), r1 = v1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
+    const float q0 = r0 - __uint_as_float(m0 & 0xffff0000u), q1 = r1 - __uint_as_float(m1 & 0xffff0000u);
+    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    mid = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+
 // 8 floats -> three planes of 8 bf16 (hi | mid | lo), element j in the j-th half-word
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
-    unsigned u[8], m[8], l[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        u[e] = __float_as_uint(v[e]);
-        const float r1 = v[e] - __uint_as_float(u[e] & 0xffff0000u);
-        m[e] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(m[e] & 0xffff0000u);
-        l[e] = __float_as_uint(r2);
-    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        hi[e] = __builtin_amdgcn_perm(u[2 * e + 1], u[2 * e], 0x07060302u);
-        mid[e] = __builtin_amdgcn_perm(m[2 * e + 1], m[2 * e], 0x07060302u);
-        lo[e] = __builtin_amdgcn_perm(l[2 * e + 1], l[2 * e], 0x07060302u);
+        unsigned a, b, c;
+        split2(v[2 * e], v[2 * e + 1], a, b, c);
+        hi[e] = a;
+        mid[e] = b;
+        lo[e] = c;
     }
 }
 
 __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst, int plane_stride) {
-    unsigned u[4], m[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        u[e] = __float_as_uint(v[e]);
-        const float r1 = v[e] - __uint_as_float(u[e] & 0xffff0000u);
-        m[e] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(m[e] & 0xffff0000u);
-        l[e] = __float_as_uint(r2);
-    }
     u32x2 hi, mid, lo;
-    hi[0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
-    hi[1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
-    mid[0] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
-    mid[1] = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
-    lo[0] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
-    lo[1] = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        unsigned a, b, c;
+        split2(v[2 * e], v[2 * e + 1], a, b, c);
+        hi[e] = a;
+        mid[e] = b;
+        lo[e] = c;
+    }
     *reinterpret_cast<u32x2*>(dst) = hi;
     *reinterpret_cast<u32x2*>(dst + plane_stride) = mid;
     *reinterpret_cast<u32x2*>(dst + 2 * plane_stride) = lo;
@@ -256,6 +254,9 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst, 
 // 64-channel slice handled by ANOTHER workgroup repeats the scores and the softmax. Tensors of 128 channels and more
 // therefore run (QB, NCT) = (1, 4): 32 queries x 128 channels per wave, which makes the matrix pipe the longer side
 // and halves the repeated work; 64-channel tensors keep (2, 2).
+#ifndef DDPM_ATTN_ABLATE
+#define DDPM_ATTN_ABLATE 0   // diagnostic builds only (wrong results): bit 0 no softmax arithmetic, bit 1 no value-product MFMAs, bit 2 no staging in the loop, bit 3 no transposed V reads in the loop; pipelined kernel: bit 4 no softmax slices, bit 5 no staging, bit 6 V fragments of the first pair only, bit 7 no barrier in the loop
+#endif
 template <int DQ, int QB, int NCT>
 __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnParams p) {
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
@@ -326,24 +327,21 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
     }
 
     f32x4 kreg[KPT], vreg[VPT];
+    // K and V rows come through a range-checked descriptor over the sample's [n][lq] block: rows past the last key
+    // and channels past the last one read as zero without a branch
+    const __amdgpu_buffer_rsrc_t rs_kv = ddpm::buffer_over(base, static_cast<long long>(p.n) * p.lq * 4ll);
     auto load_tile = [&](int j0) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (DQ / 4), c4 = f % (DQ / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (f < KF4 && j0 + row < p.n)
-                v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(j0 + row) * p.lq + p.dqp + c4 * 4);
-            kreg[i] = v;
+            kreg[i] = ddpm::buffer_load4(rs_kv, f < KF4 ? static_cast<unsigned>((j0 + row) * p.lq + p.dqp + c4 * 4) * 4u : ddpm::kOob);
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CS / 4), c4 = f % (CS / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (j0 + row < p.n && cbase + c4 * 4 < p.c)
-                v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(j0 + row) * p.lq + 2 * p.dqp + cbase + c4 * 4);
-            vreg[i] = v;
+            vreg[i] = ddpm::buffer_load4(rs_kv, cbase + c4 * 4 < p.c ? static_cast<unsigned>((j0 + row) * p.lq + 2 * p.dqp + cbase + c4 * 4) * 4u : ddpm::kOob);
         }
     };
     auto store_tile = [&](int buf) {
@@ -376,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
     for (int t = 0; t < tiles; ++t) {
         const int buf = t & 1, j0 = t * KT;
         const bool more = t + 1 < tiles;
-        if (more) load_tile(j0 + KT);
+        if (more && !(DDPM_ATTN_ABLATE & 4)) load_tile(j0 + KT);
         if (wave_active) {
             // ---- scores: lane = query, register = key rowmap(reg, h)
             f32x16 s[QB];
@@ -389,23 +387,31 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
                 bf16x8 kf[3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const bf16x8*>(&sK[buf][r * KROW + pl * KPL + kc * 32 + h * 16]);
+                auto term = [&](int pa, int pb) {
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) {
-                    auto term = [&](int pa, int pb) {
+                    for (int qb = 0; qb < QB; ++qb)
                         s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[pa], __builtin_bit_cast(bf16x8, qf[qb][kc][pb]), s[qb], 0, 0, 0);
-                    };
-                    term(2, 0);
-                    term(0, 2);
-                    term(1, 1);
-                    term(1, 0);
-                    term(0, 1);
-                    term(0, 0);
-                }
+                };
+                term(2, 0);
+                term(0, 2);
+                term(1, 1);
+                term(1, 0);
+                term(0, 1);
+                term(0, 0);
             }
             // ---- online softmax, probabilities split into three bf16 planes per 16-key chunk
             u32x4 pp[QB][2][3];
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
+                if (DDPM_ATTN_ABLATE & 1) {
+#pragma unroll
+                    for (int ck = 0; ck < 2; ++ck)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pp[qb][ck][pl][e] = __float_as_uint(s[qb][(8 * ck + 4 * (pl & 1) + e) & 15]);
+                    continue;
+                }
                 if (j0 + KT > p.n) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
@@ -440,38 +446,41 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
                     split8(v, pp[qb][ck][0], pp[qb][ck][1], pp[qb][ck][2]);
                 }
             }
-            // ---- O^T += V^T P^T
+            // ---- O^T += V^T P^T, two channel blocks at a time with their accumulators taken in turn (an MFMA that
+            // accumulates into the registers the previous one wrote waits for it)
 #pragma unroll
             for (int ck = 0; ck < 2; ++ck) {
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    bf16x8 vf[3];
+                for (int ct0 = 0; ct0 < NCT; ct0 += 2) {
+                    bf16x8 vf[2][3];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        const unsigned char* src = &sV[buf][pl * VPLANE + (16 * ck) * VROW + ct * 64 + vlane];
-                        const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(src));
-                        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(src + 8 * VROW));
-                        const s16x8 both = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-                        vf[pl] = __builtin_bit_cast(bf16x8, both);
-                    }
+                    for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) {
-                        auto term = [&](int pa, int pb) {
-                            o[qb][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[pa], __builtin_bit_cast(bf16x8, pp[qb][ck][pb]), o[qb][ct], 0, 0, 0);
-                        };
-                        term(2, 0);
-                        term(0, 2);
-                        term(1, 1);
-                        term(1, 0);
-                        term(0, 1);
-                        term(0, 0);
+                        for (int pl = 0; pl < 3; ++pl) {
+                            if ((DDPM_ATTN_ABLATE & 8) && (ck | ct0 | c2)) {
+                                vf[c2][pl] = __builtin_bit_cast(bf16x8, qf[0][0][pl]);
+                                continue;
+                            }
+                            const unsigned char* src = &sV[buf][pl * VPLANE + (16 * ck) * VROW + (ct0 + c2) * 64 + vlane];
+                            const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src));
+                            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src + 8 * VROW));
+                            vf[c2][pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+                        }
+                    const int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        if ((DDPM_ATTN_ABLATE & 2) && k < 5) continue;
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb)
+                                o[qb][ct0 + c2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c2][pa[k]], __builtin_bit_cast(bf16x8, pp[qb][ck][pb[k]]),
+                                                                                          o[qb][ct0 + c2], 0, 0, 0);
                     }
                 }
             }
         }
-        if (more) store_tile(buf ^ 1);
+        if (more && !(DDPM_ATTN_ABLATE & 4)) store_tile(buf ^ 1);
         __syncthreads();
     }
 
@@ -506,6 +515,364 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
     }
 }
 
+// Software-pipelined version of the kernel above (one 32-query block per wave). A wave of the kernel above goes
+// through its tile in phases -- scores (MFMA), softmax and splitting (VALU), value product (MFMA), staging of the
+// next tile (VALU) -- and the two waves that share a SIMD fall into step with each other, so that the matrix pipe
+// idles through every VALU phase. Here iteration t issues the value-product MFMAs of tile t one by one and puts a
+// slice of the VALU work of tile t + 1 behind each of them: its softmax (the scores of tile t + 1 are the first
+// MFMAs of the iteration, from a K tile staged one iteration further ahead, hence three K buffers), the split of its
+// probabilities, and the splitting + LDS stores of the tiles being staged. A VALU instruction issues while the MFMA
+// in front of it executes, so the wave keeps both pipes busy by itself. Same operations on the same values in the
+// same order per query as the kernel above: the results are bit-identical.
+template <int DQ, int NCT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const AttnParams p) {
+    const dim3 bid = ddpm::xcd_block();
+    constexpr int NT = 64 * NW;
+    constexpr int CS = 32 * NCT;
+    constexpr int KD = DQ < 16 ? 16 : DQ, KC = KD / 16, KPL = KD * 2, KROW = 3 * KPL + 16;
+    constexpr int VROW = CS * 2 + 64, VPLANE = KT * VROW;
+    constexpr int KF4 = KT * DQ / 4, VF4 = KT * CS / 4;
+    constexpr int KPT = (KF4 + NT - 1) / NT, VPT = VF4 / NT;
+    static_assert(VF4 % NT == 0, "V tile must split evenly over the workgroup");
+    constexpr int KBUF = KT * KROW, VBUF = 3 * VPLANE;
+    constexpr float kLog2e = 1.4426950408889634f;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    unsigned char* sK = psm;                // [3][KBUF]
+    unsigned char* sV = psm + 3 * KBUF;     // [2][VBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int b = bid.z;
+    const int cbase = bid.y * CS;
+    const int q0 = (bid.x * NW + wave) * 32;
+    const bool wave_active = q0 < p.n;          // wave-uniform
+    const float* base = p.qkv + static_cast<int64_t>(b) * p.n * p.lq;
+
+    if (DQ < 16) {   // the upper half of the padded depth stays zero
+        for (int i = tid; i < 3 * KBUF / 4; i += NT) reinterpret_cast<unsigned*>(sK)[i] = 0u;
+    }
+
+    u32x4 qf[KC][3];
+    {
+        const int qi = q0 + r;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            const int d0 = 16 * kc + 8 * h;
+            if (qi < p.n && d0 < DQ) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(qi) * p.lq + d0);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(qi) * p.lq + d0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = x0[j];
+                    v[4 + j] = x1[j];
+                }
+            }
+            split8(v, qf[kc][0], qf[kc][1], qf[kc][2]);
+        }
+    }
+
+    f32x16 o[NCT];
+#pragma unroll
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    f32x4 kreg[KPT], vreg[VPT];
+    // K and V rows come through a range-checked descriptor over the sample's [n][lq] block: rows past the last key
+    // and channels past the last one read as zero without a branch
+    const __amdgpu_buffer_rsrc_t rs_kv = ddpm::buffer_over(base, static_cast<long long>(p.n) * p.lq * 4ll);
+    auto load_k = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int f = tid + NT * i;
+            const int row = f / (DQ / 4), c4 = f % (DQ / 4);
+            kreg[i] = ddpm::buffer_load4(rs_kv, f < KF4 ? static_cast<unsigned>((j0 + row) * p.lq + p.dqp + c4 * 4) * 4u : ddpm::kOob);
+        }
+    };
+    auto load_v = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int f = tid + NT * i;
+            const int row = f / (CS / 4), c4 = f % (CS / 4);
+            vreg[i] = ddpm::buffer_load4(rs_kv, cbase + c4 * 4 < p.c ? static_cast<unsigned>((j0 + row) * p.lq + 2 * p.dqp + cbase + c4 * 4) * 4u : ddpm::kOob);
+        }
+    };
+    auto store_k1 = [&](int i, unsigned char* dst) {
+        const int f = tid + NT * i;
+        const int row = f / (DQ / 4), c4 = f % (DQ / 4);
+        if (f < KF4) split4_store(kreg[i], dst + row * KROW + c4 * 8, KPL);
+    };
+    auto store_v1 = [&](int i, unsigned char* dst) {
+        const int f = tid + NT * i;
+        const int row = f / (CS / 4), c4 = f % (CS / 4);
+        split4_store(vreg[i], dst + row * VROW + c4 * 8, VPLANE);
+    };
+
+    const int vlane = (4 * h + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const int tiles = (p.n + KT - 1) / KT;
+
+    // scores of one tile: lane = query, register = key rowmap(reg, h)
+    auto scores = [&](const unsigned char* kb, f32x16& s) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            bf16x8 kf[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const bf16x8*>(kb + r * KROW + pl * KPL + kc * 32 + h * 16);
+            auto term = [&](int pa, int pb) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[pa], __builtin_bit_cast(bf16x8, qf[kc][pb]), s, 0, 0, 0);
+            };
+            term(2, 0);
+            term(0, 2);
+            term(1, 1);
+            term(1, 0);
+            term(0, 1);
+            term(0, 0);
+        }
+    };
+
+    // The softmax of one tile in 29 slices (the arithmetic of the kernel above, cut up): s holds scores on entry and
+    // probabilities after slice 19; pn receives their planes; alpha the factor that the accumulators owe.
+    constexpr int SM = 29;
+    float mt = 0.f, m_new = 0.f, alpha = 1.f, ps = 0.f;
+    auto softmax_slice = [&](auto ic, f32x16& s, u32x4 (&pn)[2][3], int j0) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i == 0) {
+            if (j0 + KT > p.n) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (j0 + rowmap(e, h) >= p.n) s[e] = -INFINITY;
+            }
+            mt = s[0];
+#pragma unroll
+            for (int e = 1; e < 6; ++e) mt = fmaxf(mt, s[e]);
+        } else if constexpr (i == 1) {
+#pragma unroll
+            for (int e = 6; e < 11; ++e) mt = fmaxf(mt, s[e]);
+        } else if constexpr (i == 2) {
+#pragma unroll
+            for (int e = 11; e < 16; ++e) mt = fmaxf(mt, s[e]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+        } else if constexpr (i == 3) {
+            m_new = fmaxf(m_run, mt);
+            alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);   // 0 on the first tile
+            ps = 0.f;
+        } else if constexpr (i < 20) {
+            constexpr int e = i - 4;
+            s[e] = __builtin_amdgcn_exp2f((s[e] - m_new) * kLog2e);
+            ps += s[e];
+        } else if constexpr (i == 20) {
+            ps += __shfl_xor(ps, 32);
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+        } else {
+            // elements 2j, 2j + 1 -> one 32-bit word of each plane
+            constexpr int j = i - 21, ck = j >> 2, w = j & 3;
+            unsigned a, b, c;
+            split2(s[2 * j], s[2 * j + 1], a, b, c);
+            pn[ck][0][w] = a;
+            pn[ck][1][w] = b;
+            pn[ck][2][w] = c;
+        }
+    };
+
+    auto read_vf = [&](bf16x8 (&vf)[3], const unsigned char* vb, int blk) {
+        const int ck = blk / NCT, ct = blk % NCT;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const unsigned char* src = vb + pl * VPLANE + (16 * ck) * VROW + ct * 64 + vlane;
+            const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src));
+            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src + 8 * VROW));
+            vf[pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+
+    // ---- prologue: K(0), V(0), K(1) staged; scores and softmax of tile 0
+    load_k(0);
+    load_v(0);
+    __syncthreads();   // the zero fill of sK, if any
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) store_k1(i, sK);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) store_v1(i, sV);
+    if (tiles > 1) {
+        load_k(KT);
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) store_k1(i, sK + KBUF);
+    }
+    __syncthreads();
+
+    u32x4 pp[2][3];
+    if (wave_active) {
+        f32x16 s0;
+        scores(sK, s0);
+        ddpm::static_for<SM>([&](auto ic) { softmax_slice(ic, s0, pp, 0); });
+        // alpha = exp2(-inf) = 0 and the accumulators are zero: nothing owed
+    }
+
+    // The value product takes its (16-key chunk, 32-channel block) pieces two at a time and alternates between their
+    // accumulators, and the scores of the next tile are slipped in between the first of them: an MFMA that accumulates
+    // into the registers the previous one wrote waits for it (measured: a chain of dependent v_mfma_f32_32x32x16_bf16
+    // runs at half the rate of two interleaved chains).
+    constexpr int NB = 2 * NCT;         // pieces
+    constexpr int M = 6 * NB;           // their MFMAs
+    constexpr int NS = 6 * KC;          // MFMAs of one tile of scores
+    constexpr int LEAD = NS + 2;        // value-product MFMAs in front of the first softmax slice (the scores must have left the pipe)
+    static_assert(NCT % 2 == 0 && LEAD < M, "pairs of channel blocks; the scores fit in front of the softmax");
+    auto body = [&](auto next_tag, int t) {
+        constexpr bool NEXT = decltype(next_tag)::value;
+        const int j0n = (t + 1) * KT;
+        const bool more2 = t + 2 < tiles;
+        const unsigned char* vb = sV + (t & 1) * VBUF;
+        unsigned char* vnext = sV + ((t + 1) & 1) * VBUF;
+        unsigned char* knext2 = sK + ((t + 2) % 3) * KBUF;
+        if (NEXT && !(DDPM_ATTN_ABLATE & 32)) {
+            load_v(j0n);
+            if (more2) load_k(j0n + KT);
+        }
+        constexpr int P = NEXT ? SM + VPT + KPT : 0;     // VALU slices of this iteration
+        if (wave_active) {
+            f32x16 sn;
+            u32x4 pn[2][3];
+            bf16x8 vf[2][2][3], kf[KC][3];
+            read_vf(vf[0][0], vb, 0);
+            read_vf(vf[0][1], vb, 1);
+            if (NEXT) {
+                const unsigned char* kb = sK + ((t + 1) % 3) * KBUF;
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) kf[kc][pl] = *reinterpret_cast<const bf16x8*>(kb + r * KROW + pl * KPL + kc * 32 + h * 16);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sn[e] = 0.f;
+            }
+            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+            ddpm::static_for<M>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int pr = i / 12, k = (i % 12) >> 1, c2 = i & 1;
+                constexpr int blk = 2 * pr + c2, ck = blk / NCT, ct = blk % NCT;
+                if constexpr (i % 12 == 0 && 2 * pr + 2 < NB) {
+                    if constexpr (DDPM_ATTN_ABLATE & 64) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) vf[(pr + 1) & 1][q / 3][q % 3] = vf[pr & 1][q / 3][q % 3];
+                    } else {
+                        read_vf(vf[(pr + 1) & 1][0], vb, 2 * pr + 2);
+                        read_vf(vf[(pr + 1) & 1][1], vb, 2 * pr + 3);
+                    }
+                }
+                o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[pr & 1][c2][pa[k]], __builtin_bit_cast(bf16x8, pp[ck][pb[k]]), o[ct], 0, 0, 0);
+                if constexpr (NEXT) {
+                    if constexpr (i < NS)
+                        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i / 6][pa[i % 6]], __builtin_bit_cast(bf16x8, qf[i / 6][pb[i % 6]]), sn, 0, 0, 0);
+                    constexpr int lo = i < LEAD ? 0 : (i - LEAD) * P / (M - LEAD);
+                    constexpr int hi = i < LEAD ? 0 : (i + 1 == M ? P : (i + 1 - LEAD) * P / (M - LEAD));
+                    ddpm::static_for<hi - lo>([&](auto dc) {
+                        constexpr int sl = lo + decltype(dc)::value;
+                        if constexpr (sl < SM) {
+                            if constexpr (!(DDPM_ATTN_ABLATE & 16)) softmax_slice(std::integral_constant<int, sl>{}, sn, pn, j0n);
+                            else if constexpr (sl == 0) {
+#pragma unroll
+                                for (int q = 0; q < 24; ++q) pn[q / 12][(q / 4) % 3][q & 3] = __float_as_uint(sn[q & 15]);
+                            }
+                        } else if constexpr (DDPM_ATTN_ABLATE & 32) {
+                        } else if constexpr (sl < SM + VPT) store_v1(sl - SM, vnext);
+                        else if (more2) store_k1(sl - SM - VPT, knext2);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            if (NEXT) {
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {   // the running maximum moved for some query
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) o[ct][e] *= alpha;
+                }
+#pragma unroll
+                for (int ck = 0; ck < 2; ++ck)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) pp[ck][pl] = pn[ck][pl];
+            }
+        } else if (NEXT) {
+            // (the registers pass through an empty asm so that this copy of the splitting code is not merged with the
+            // slices above and hoisted in front of both, where it would wait for the loads at the top of the iteration)
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                asm volatile("" : "+v"(vreg[i]));
+                store_v1(i, vnext);
+            }
+            if (more2) {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    asm volatile("" : "+v"(kreg[i]));
+                    store_k1(i, knext2);
+                }
+            }
+        }
+    };
+    for (int t = 0; t + 1 < tiles; ++t) {
+        body(std::true_type{}, t);
+        if (!(DDPM_ATTN_ABLATE & 128)) __syncthreads();
+    }
+    body(std::false_type{}, tiles - 1);
+
+    if (!wave_active) return;
+    const float g = p.gamma[0];
+    const int qi = q0 + r;
+    if (qi >= p.n) return;
+    const float inv_l = 1.0f / l_run;
+    const int64_t pix = static_cast<int64_t>(b) * p.n + qi;
+    if (p.lse && h == 0 && bid.y == 0) p.lse[pix] = m_run + logf(l_run);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int c = cbase + ct * 32 + gq * 8 + h * 4;   // channels c..c+3 = registers 4gq..4gq+3
+            if (c >= p.c) continue;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + pix * p.ldx + c);
+            f32x4 te = {0.f, 0.f, 0.f, 0.f};
+            if (p.temb) te = *reinterpret_cast<const f32x4*>(p.temb + static_cast<int64_t>(b) * p.c + c);
+            f32x4 a, y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = o[ct][gq * 4 + e] * inv_l;
+                y[e] = (g * a[e] + xv[e]) + te[e];
+            }
+            if (p.attn_raw) *reinterpret_cast<f32x4*>(p.attn_raw + pix * p.c + c) = a;
+            *reinterpret_cast<f32x4*>(p.out + pix * p.ldo + c) = y;
+        }
+    }
+}
+
+template <int DQ, int NCT, int NW>
+int launch_x3p(const AttnParams& p, int batch, hipStream_t s) {
+    constexpr int KD = DQ < 16 ? 16 : DQ;
+    constexpr int lds = 3 * KT * (3 * KD * 2 + 16) + 2 * 3 * KT * (32 * NCT * 2 + 64);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_x3p_kernel<DQ, NCT, NW>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return ddpm::fail_invalid("LDS size for the attention forward");
+    const dim3 g((p.n + 32 * NW - 1) / (32 * NW), (p.c + 32 * NCT - 1) / (32 * NCT), batch);
+    attention_fwd_x3p_kernel<DQ, NCT, NW><<<g, 64 * NW, lds, s>>>(p);
+    return ddpm::check_launch("attention_fwd_x3p_kernel");
+}
+
+// DDPM_ATTN_PIPE=0 (read once) selects the phase-by-phase kernel instead of the software-pipelined one: a diagnostic
+// switch for A/B measurements.
+inline bool pipelined_attention() {
+    static const bool on = [] {
+        const char* e = getenv("DDPM_ATTN_PIPE");
+        return !(e && strcmp(e, "0") == 0);
+    }();
+    return on;
+}
+
 // DDPM_ATTN_WIDE=0 (read once) keeps tensors of 128 channels and more on the 64-channel configuration: a diagnostic
 // switch for A/B measurements.
 inline bool wide_attention() {
@@ -520,6 +887,11 @@ template <int DQ>
 int launch_dq(const AttnParams& p, int batch, hipStream_t s) {
     if constexpr (DQ <= 64) {   // 128 query channels (C = 1024): only the bottleneck has them, its maps are short
       if (ddpm::split_math() && p.n >= 128 && p.c >= 64) {
+        // 128 channels and more: the software-pipelined kernel (2-6 % faster there; 64-channel tensors are faster with two
+        // query blocks per wave, and with 64 query channels the scores alone are half of a tile's MFMAs)
+        if constexpr (DQ <= 32) {
+            if (p.c >= 128 && pipelined_attention()) return launch_x3p<DQ, 4, 4>(p, batch, s);
+        }
         if (p.c >= 128 && wide_attention()) {
             const dim3 g((p.n + 127) / 128, (p.c + 127) / 128, batch);
             attention_fwd_x3_kernel<DQ, 1, 4><<<g, 256, 0, s>>>(p);

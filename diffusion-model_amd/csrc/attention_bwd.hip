@@ -768,16 +768,31 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
             load_split8(base + static_cast<int64_t>(kj) * p.lq + 2 * DQ + 16 * kc + 8 * h, k_ok, vf[kc][0], vf[kc][1], vf[kc][2], 1.0f);
     }
 
-    f32x16 dv[DV ? NCT : 1], dk;
+    // An MFMA that accumulates into the registers the previous one wrote waits for it (a chain of dependent
+    // v_mfma_f32_32x32x16_bf16 runs at half the rate of two interleaved chains), so every product below alternates
+    // between two accumulators: dK keeps one per 16-query chunk and adds them at the end, the scores and dP keep two
+    // partial sums per tile, dV takes its channel blocks in pairs.
+    f32x16 dv[DV ? NCT : 1], dk2[2];
 #pragma unroll
     for (int t = 0; t < (DV ? NCT : 1); ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dv[t][e] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dk[e] = 0.f;
+    for (int e = 0; e < 16; ++e) {
+        dk2[0][e] = 0.f;
+        dk2[1][e] = 0.f;
+    }
+    constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
 
     auto dofs = [](int row, int ch) { return DV ? swz(row, ch) : row * DROW + 16 * ch; };
 
+    // The tiles that stream past come through range-checked descriptors over the sample's rows: rows past the last
+    // query read as zero without a branch (with branches around its loads the compiler cannot count the outstanding
+    // ones and waits for all of them at the first use)
+    const __amdgpu_buffer_rsrc_t rs_dy = ddpm::buffer_over(dyb, (static_cast<long long>(p.n) * p.ldd - c0) * 4ll);
+    const __amdgpu_buffer_rsrc_t rs_q = ddpm::buffer_over(base, static_cast<long long>(p.n) * p.lq * 4ll);
+    const __amdgpu_buffer_rsrc_t rs_l = ddpm::buffer_over(lseb, p.n * 4ll);
+    const __amdgpu_buffer_rsrc_t rs_e = ddpm::buffer_over(eb, p.n * 4ll);
     f32x4 doreg[DOPT], qreg;
     float lreg = 0.f, dreg = 0.f;
     auto load_tile = [&](int i0) {
@@ -785,28 +800,22 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
         for (int i = 0; i < DOPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CT / 4), c4 = f % (CT / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (i0 + row < p.n) v = *reinterpret_cast<const f32x4*>(dyb + static_cast<int64_t>(i0 + row) * p.ldd + c4 * 4);
-            doreg[i] = v * g;
+            doreg[i] = ddpm::buffer_load4(rs_dy, static_cast<unsigned>((i0 + row) * p.ldd + c4 * 4) * 4u);
         }
-        if (tid < QF4) {
+        {
             const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (i0 + row < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(i0 + row) * p.lq + c4 * 4);
-            qreg = v;
+            qreg = ddpm::buffer_load4(rs_q, tid < QF4 ? static_cast<unsigned>((i0 + row) * p.lq + c4 * 4) * 4u : ddpm::kOob);
         }
-        if (tid < TQ) {
-            const bool ok = i0 + tid < p.n;
-            lreg = ok ? lseb[i0 + tid] : 0.f;
-            dreg = ok ? g * eb[i0 + tid] : 0.f;
-        }
+        const unsigned lo = tid < TQ ? static_cast<unsigned>(i0 + tid) * 4u : ddpm::kOob;
+        lreg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_l, lo, 0, 0));
+        dreg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_e, lo, 0, 0));
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < DOPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CT / 4), c4 = f % (CT / 4);
-            split4_store(doreg[i], sDO + buf * 3 * DPLANE + dofs(row, c4 >> 1) + 8 * (c4 & 1), DPLANE);
+            split4_store(doreg[i] * g, sDO + buf * 3 * DPLANE + dofs(row, c4 >> 1) + 8 * (c4 & 1), DPLANE);
         }
         if (tid < QF4) {
             const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
@@ -814,7 +823,7 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
         }
         if (tid < TQ) {
             sL[buf * TQ + tid] = lreg;
-            sD[buf * TQ + tid] = dreg;
+            sD[buf * TQ + tid] = g * dreg;
         }
     };
 
@@ -838,31 +847,49 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
         if (wave_active) {
             const unsigned char* q = sQ + buf * 3 * QPLANE;
             const unsigned char* dO = sDO + buf * 3 * DPLANE;
-            f32x16 s, dp;
+            f32x16 s, s1, dp, dp1;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
-            auto six = [&](f32x16& acc, const bf16x8 (&a)[3], const u32x4 (&bb)[3]) {
-                const int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[k]], __builtin_bit_cast(bf16x8, bb[pb[k]]), acc, 0, 0, 0);
-            };
-#pragma unroll
-            for (int kq = 0; kq < KQ; ++kq) {   // S = Q K^T: rows = queries (this tile), columns = keys (lanes)
-                bf16x8 a[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(q + pl * QPLANE + r * QROW + kq * 32 + h * 16);
-                six(s, a, kf[kq]);
+            for (int e = 0; e < 16; ++e) {
+                s[e] = 0.f;
+                s1[e] = 0.f;
+                dp[e] = 0.f;
+                dp1[e] = 0.f;
             }
+            auto mma = [&](f32x16& acc, const bf16x8& a, const u32x4& bb) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bb), acc, 0, 0, 0);
+            };
+            // S = Q K^T: rows = queries (this tile), columns = keys (lanes)
+            bf16x8 aq[KQ][3];
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) aq[kq][pl] = *reinterpret_cast<const bf16x8*>(q + pl * QPLANE + r * QROW + kq * 32 + h * 16);
             if (DK) {
+                // dP = dO V^T, two 16-channel chunks at a time into two partial sums; the MFMAs of the scores (one chain)
+                // go between the first of them
+                static_assert(!DK || (KCV % 2 == 0 && KQ <= KCV / 2), "chunk pairs; the scores fit between them");
 #pragma unroll
-                for (int kc = 0; kc < KCV; ++kc) {   // dP = dO V^T
-                    bf16x8 a[3];
+                for (int kc = 0; kc < KCV; kc += 2) {
+                    bf16x8 a[2][3];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        a[pl] = *reinterpret_cast<const bf16x8*>(dO + pl * DPLANE + r * DROW + 16 * ((2 * kc + h) ^ sw_row));
-                    six(dp, a, vf[kc]);
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            a[c2][pl] = *reinterpret_cast<const bf16x8*>(dO + pl * DPLANE + r * DROW + 16 * ((2 * (kc + c2) + h) ^ sw_row));
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        if (kc / 2 < KQ) mma(s, aq[kc / 2 < KQ ? kc / 2 : 0][pa[k]], kf[kc / 2 < KQ ? kc / 2 : 0][pb[k]]);
+                        mma(dp, a[0][pa[k]], vf[kc][pb[k]]);
+                        mma(dp1, a[1][pa[k]], vf[kc + 1][pb[k]]);
+                    }
                 }
+                dp += dp1;
+            } else {
+#pragma unroll
+                for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) mma((k & 1) ? s1 : s, aq[kq][pa[k]], kf[kq][pb[k]]);
+                s += s1;
             }
             // P and dS, split into planes per 16-query chunk (register e <-> query rowmap(e, h))
             u32x4 pp[2][3], ds[2][3];
@@ -886,31 +913,45 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
                 if (DV) split8(pv, pp[ck][0], pp[ck][1], pp[ck][2]);
                 if (DK) split8(dsv, ds[ck][0], ds[ck][1], ds[ck][2]);
             }
+            if (DV) {
+                // dV^T += dO^T P : A = dO^T through transposed reads (rows = channels of block ct, k = queries)
+                static_assert(!DV || NCT % 2 == 0, "channel blocks are taken in pairs");
 #pragma unroll
-            for (int ck = 0; ck < 2; ++ck) {
-                if (DV) {
-                    // dV^T += dO^T P : A = dO^T through transposed reads (rows = channels of block ct, k = queries)
+                for (int ck = 0; ck < 2; ++ck) {
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) {
-                        bf16x8 a[3];
+                    for (int ct = 0; ct < NCT; ct += 2) {
+                        bf16x8 a[2][3];
                         const int row0 = 16 * ck + 4 * h + tq;
-                        const int ch0 = 4 * ct + 2 * tg + (tp >> 1);
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) {
-                            const unsigned char* pb = dO + pl * DPLANE + 8 * (tp & 1);
-                            a[pl] = tr_pair(pb + 256 * row0 + 16 * (ch0 ^ tsw0), pb + 256 * (row0 + 8) + 16 * (ch0 ^ tsw1));
+                        for (int c2 = 0; c2 < 2; ++c2) {
+                            const int ch0 = 4 * (ct + c2) + 2 * tg + (tp >> 1);
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) {
+                                const unsigned char* pbase = dO + pl * DPLANE + 8 * (tp & 1);
+                                a[c2][pl] = tr_pair(pbase + 256 * row0 + 16 * (ch0 ^ tsw0), pbase + 256 * (row0 + 8) + 16 * (ch0 ^ tsw1));
+                            }
                         }
-                        six(dv[ct], a, pp[ck]);
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            mma(dv[ct], a[0][pa[k]], pp[ck][pb[k]]);
+                            mma(dv[ct + 1], a[1][pa[k]], pp[ck][pb[k]]);
+                        }
                     }
                 }
-                if (DK) {   // dK^T += Q^T dS
-                    bf16x8 a[3];
+            }
+            if (DK) {   // dK^T += Q^T dS, the two 16-query chunks side by side
+                bf16x8 a[2][3];
+#pragma unroll
+                for (int ck = 0; ck < 2; ++ck)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
-                        const unsigned char* pb = q + pl * QPLANE + 16 * ck * QROW + qtr;
-                        a[pl] = tr_pair(pb, pb + 8 * QROW);
+                        const unsigned char* pbase = q + pl * QPLANE + 16 * ck * QROW + qtr;
+                        a[ck][pl] = tr_pair(pbase, pbase + 8 * QROW);
                     }
-                    six(dk, a, ds[ck]);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    mma(dk2[0], a[0][pa[k]], ds[0][pb[k]]);
+                    mma(dk2[1], a[1][pa[k]], ds[1][pb[k]]);
                 }
             }
         }
@@ -931,6 +972,7 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
             }
     }
     if (DK) {
+        const f32x16 dk = dk2[0] + dk2[1];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int d = gq * 8 + h * 4;
@@ -949,7 +991,7 @@ constexpr int dkv_x3_lds() {
 
 // Query-side gradient of 32 queries per wave (dO of all CT = C channels in registers).
 template <int DQ, int CT>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams p) {
+__global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(const BwdParams p) {
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     constexpr int KCV = CT / 16;
     constexpr int KD = DQ < 16 ? 16 : DQ, KQ = KD / 16;
@@ -989,25 +1031,28 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams 
     const float lse_i = q_ok ? p.lse[static_cast<int64_t>(b) * p.n + qi] : 0.f;
     const float d_i = q_ok ? g * p.e[static_cast<int64_t>(b) * p.n + qi] : 0.f;
 
-    f32x16 dq;
+    // (two accumulators per product, taken in turn: see the key-side kernel)
+    f32x16 dq2[2];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+    for (int e = 0; e < 16; ++e) {
+        dq2[0][e] = 0.f;
+        dq2[1][e] = 0.f;
+    }
+    constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
 
+    // K and V rows through a range-checked descriptor over the sample's [n][lq] block: no branch around the loads
+    const __amdgpu_buffer_rsrc_t rs_kv = ddpm::buffer_over(base, static_cast<long long>(p.n) * p.lq * 4ll);
     f32x4 kreg, vreg[VPT];
     auto load_tile = [&](int j0) {
-        if (tid < KF4) {
+        {
             const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (j0 + row < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(j0 + row) * p.lq + DQ + c4 * 4);
-            kreg = v;
+            kreg = ddpm::buffer_load4(rs_kv, tid < KF4 ? static_cast<unsigned>((j0 + row) * p.lq + DQ + c4 * 4) * 4u : ddpm::kOob);
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CT / 4), c4 = f % (CT / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (j0 + row < p.n) v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(j0 + row) * p.lq + 2 * DQ + c4 * 4);
-            vreg[i] = v;
+            vreg[i] = ddpm::buffer_load4(rs_kv, static_cast<unsigned>((j0 + row) * p.lq + 2 * DQ + c4 * 4) * 4u);
         }
     };
     auto store_tile = [&](int buf) {
@@ -1039,29 +1084,40 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams 
         if (wave_active) {
             const unsigned char* k = sK + buf * 3 * KPLANE;
             const unsigned char* v = sV + buf * 3 * VPLANE;
-            f32x16 s, dp;
+            f32x16 s, dp, dp1;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
-            auto six = [&](f32x16& acc, const bf16x8 (&a)[3], const u32x4 (&bb)[3]) {
-                const int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int kk = 0; kk < 6; ++kk)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[kk]], __builtin_bit_cast(bf16x8, bb[pb[kk]]), acc, 0, 0, 0);
+            for (int e = 0; e < 16; ++e) {
+                s[e] = 0.f;
+                dp[e] = 0.f;
+                dp1[e] = 0.f;
+            }
+            auto mma = [&](f32x16& acc, const bf16x8& a, const u32x4& bb) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bb), acc, 0, 0, 0);
             };
+            // S^T = K Q^T: rows = keys (this tile), columns = queries (lanes)
+            bf16x8 ak[KQ][3];
 #pragma unroll
-            for (int kq = 0; kq < KQ; ++kq) {   // S^T = K Q^T: rows = keys (this tile), columns = queries (lanes)
-                bf16x8 a[3];
+            for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(k + pl * KPLANE + r * KROW + kq * 32 + h * 16);
-                six(s, a, qf[kq]);
+                for (int pl = 0; pl < 3; ++pl) ak[kq][pl] = *reinterpret_cast<const bf16x8*>(k + pl * KPLANE + r * KROW + kq * 32 + h * 16);
+            // dP^T = V dO^T, two 16-channel chunks at a time into two partial sums; the MFMAs of the scores (one chain) go
+            // between the first of them
+            static_assert(KCV % 2 == 0 && KQ <= KCV / 2, "chunk pairs; the scores fit between them");
+#pragma unroll
+            for (int kc = 0; kc < KCV; kc += 2) {
+                bf16x8 a[2][3];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[c2][pl] = *reinterpret_cast<const bf16x8*>(v + pl * VPLANE + r * VROW + (kc + c2) * 32 + h * 16);
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) {
+                    if (kc / 2 < KQ) mma(s, ak[kc / 2 < KQ ? kc / 2 : 0][pa[kk]], qf[kc / 2 < KQ ? kc / 2 : 0][pb[kk]]);
+                    mma(dp, a[0][pa[kk]], dof[kc][pb[kk]]);
+                    mma(dp1, a[1][pa[kk]], dof[kc + 1][pb[kk]]);
+                }
             }
-#pragma unroll
-            for (int kc = 0; kc < KCV; ++kc) {   // dP^T = V dO^T
-                bf16x8 a[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(v + pl * VPLANE + r * VROW + kc * 32 + h * 16);
-                six(dp, a, dof[kc]);
-            }
+            dp += dp1;
             u32x4 ds[2][3];
 #pragma unroll
             for (int ck = 0; ck < 2; ++ck) {
@@ -1075,15 +1131,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams 
                 }
                 split8(dsv, ds[ck][0], ds[ck][1], ds[ck][2]);
             }
+            {   // dQ^T += K^T dS^T, the two 16-key chunks side by side
+                bf16x8 a[2][3];
 #pragma unroll
-            for (int ck = 0; ck < 2; ++ck) {   // dQ^T += K^T dS^T
-                bf16x8 a[3];
+                for (int ck = 0; ck < 2; ++ck)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    const unsigned char* pb = k + pl * KPLANE + 16 * ck * KROW + ktr;
-                    a[pl] = tr_pair(pb, pb + 8 * KROW);
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const unsigned char* pbase = k + pl * KPLANE + 16 * ck * KROW + ktr;
+                        a[ck][pl] = tr_pair(pbase, pbase + 8 * KROW);
+                    }
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) {
+                    mma(dq2[0], a[0][pa[kk]], ds[0][pb[kk]]);
+                    mma(dq2[1], a[1][pa[kk]], ds[1][pb[kk]]);
                 }
-                six(dq, a, ds[ck]);
             }
         }
         if (more) store_tile(buf ^ 1);
@@ -1091,6 +1152,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x3_kernel(const BwdParams 
     }
     if (!wave_active || !q_ok) return;
     float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + qi) * p.lq;
+    const f32x16 dq = dq2[0] + dq2[1];
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
         const int d = gq * 8 + h * 4;

@@ -6,10 +6,23 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
+#include <utility>
 
 #include "../../include/ddpm_mi355x.h"
 
 namespace ddpm {
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order: a loop whose index is a compile-time
+// constant in the body (for `if constexpr` and array indices) without relying on the optimiser's unrolling.
+template <typename F, int... I>
+__host__ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__host__ __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 void set_error(const char* fmt, ...);
 
@@ -55,6 +68,19 @@ inline bool small_attention() {
 }
 
 #ifdef __HIPCC__
+// Range-checked global loads: a buffer descriptor over [base, base + bytes); any offset at or beyond `bytes` (such as
+// kOob) reads as zero, so a guarded load needs no branch -- and without branches around its loads the compiler can count
+// the outstanding ones exactly instead of waiting for all of them at the first use.
+constexpr unsigned kOob = 0x80000000u;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_over(const float* base, long long bytes) {
+    const unsigned n = bytes > 0x7fffffffll ? 0x7fffffffu : static_cast<unsigned>(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ f32x4_t buffer_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_offset) {
+    return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, byte_offset, 0, 0));
+}
+
 // Workgroups are dispatched in linear order (x fastest) and handed to the 8 XCDs round-robin, and every
 // XCD has its own L2. This returns the block index a kernel should WORK on so that consecutive linear
 // indices (the workgroups that share a sample's operands) run on ONE XCD and find each other's data in
