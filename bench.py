@@ -408,8 +408,10 @@ class Job:
                 f = line.split()
                 if len(f) > 4 and kernel_symbol in line and f[0].isdigit():
                     traffic = int(float(f[3]) * 1e6)
-                    traffic_src = ("bytes per launch, mean over this kernel's launches of one step: rocprofv3 --pmc FETCH_SIZE (x 2, the gfx950 "
-                                   "correction for wide loads) + WRITE_SIZE in separate passes, profiles/" + os.path.basename(tfile))
+                    traffic_src = ("bytes per launch, mean over this kernel's launches of one step: rocprofv3 --pmc FETCH_SIZE (x the factor "
+                                   "calibrated for this kernel's access pattern on a known byte count, tools/pmc_calibrate.sh: FETCH_SIZE "
+                                   "counts 64 bytes per read request of any size) + WRITE_SIZE in separate passes, profiles/" +
+                                   os.path.basename(tfile))
                     break
         split = "split-bf16" in dom[0]
         return {
