@@ -38,6 +38,7 @@ struct WgradParams {
     int k_total, k_chunk, splits;
     int m_tiles, n_tiles;
     int work;                 // workgroups with work (the grid is rounded up to a multiple of 8)
+    int tap_groups;           // work items along the tap axis: taps, or ceil(taps / 2) when a tile holds two taps
 };
 
 constexpr unsigned OOB = 0x80000000u;  // offsets at or beyond the buffer descriptor's range read as zero
@@ -248,8 +249,14 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst) 
     *reinterpret_cast<u32x2*>(dst + 2 * XPLANE) = lo;
 }
 
-template <int MODE>
+// PAIR (3x3 only): a layer with 64 channels on one side would leave half of the 128 x 128 tile empty. Instead the
+// tile's two 64-wide halves on that side take TWO CONSECUTIVE TAPS of the same 64 channels (five work items along the
+// tap axis instead of nine, the odd one half empty). PAIR = 1: 64 input channels, the halves of the B tile are X at
+// the two taps' offsets. PAIR = 2: 64 output channels; the B tile must be common to both halves, so the sum runs over
+// X's pixels q with A = dY at q - offset of the half's tap (the same products, enumerated from the other side).
+template <int MODE, int PAIR = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams p) {
+    static_assert(PAIR == 0 || MODE == WG_CONV3, "two taps per tile exist for the 3x3 convolution only");
     constexpr int BT = 128;
     constexpr int F4R = BT / 4;           // float4 per tile row
     constexpr int LPT = XKP * F4R / 256;  // float4 loads per thread per operand (2)
@@ -264,8 +271,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
     if (id >= p.work) return;
     const int nt = id % p.n_tiles; id /= p.n_tiles;
     const int mt = id % p.m_tiles; id /= p.m_tiles;
-    const int tap = id % p.taps;
-    const int split = id / p.taps;
+    const int tg = id % p.tap_groups;
+    const int split = id / p.tap_groups;
     const int m0 = mt * BT, n0 = nt * BT;
     const int k_begin = split * p.k_chunk;
     const int k_end = min(p.k_total, k_begin + p.k_chunk);
@@ -274,10 +281,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
+    const int row0 = tid / F4R, c4 = tid % F4R;
+    // the tap this THREAD loads for (its column half decides with PAIR), and the tap this WAVE accumulates
+    const int tap = PAIR ? 2 * tg + (c4 >> 4) : tg;
+    const int wave_tap = PAIR == 1 ? 2 * tg + wn : (PAIR == 2 ? 2 * tg + wm : tg);
+    const bool tap_ok = tap < p.taps;
     int dy = 0, dx = 0;
     if (MODE == WG_CONV3) {
         dy = tap / 3 - 1;
         dx = tap % 3 - 1;
+        if (PAIR == 2) {   // dY is the shifted operand, by the opposite offset
+            dy = -dy;
+            dx = -dx;
+        }
     }
     const int per = p.h * p.w;
 
@@ -290,9 +306,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a + a_base * p.lda, (a_pixels - a_base) * p.lda * 4ll);
     const int base_i = static_cast<int>(base_pix);
 
-    const int row0 = tid / F4R, c4 = tid % F4R;
-    const unsigned ca = m0 + c4 * 4 < p.m_total ? static_cast<unsigned>(m0 + c4 * 4) * 4u : OOB;
-    const unsigned cb = n0 + c4 * 4 < p.n_total ? static_cast<unsigned>(n0 + c4 * 4) * 4u : OOB;
+    const int cma = PAIR == 2 ? (c4 & 15) * 4 : m0 + c4 * 4;    // this thread's first channel of A and of B
+    const int cnb = PAIR == 1 ? (c4 & 15) * 4 : n0 + c4 * 4;
+    const unsigned ca = cma < p.m_total && (PAIR != 2 || tap_ok) ? static_cast<unsigned>(cma) * 4u : OOB;
+    const unsigned cb = cnb < p.n_total && (PAIR != 1 || tap_ok) ? static_cast<unsigned>(cnb) * 4u : OOB;
     // Per-thread walk over its pixels (one every XKP per step), kept as (x, y) inside the image plus
     // running byte offsets, so that a step costs adds, compares and selects only: advancing XKP pixels
     // is q16 rows and r16 columns, with one carry each into the row and the image.
@@ -309,6 +326,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
         if (MODE == WG_CONVT) {
             const int oy = 2 * py[i] + (tap >> 1) + p.off_y, ox = 2 * px[i] + (tap & 1) + p.off_x;
             oa_run[i] = static_cast<unsigned>((bi * p.a_h + oy) * p.a_w + ox) * p.lda * 4u + ca;
+            ob_run[i] = static_cast<unsigned>(pk - base_i) * p.ldb * 4u + cb;
+        } else if (PAIR == 2) {
+            oa_run[i] = static_cast<unsigned>(pk - base_i + dy * p.w + dx) * p.lda * 4u + ca;
             ob_run[i] = static_cast<unsigned>(pk - base_i) * p.ldb * 4u + cb;
         } else {
             oa_run[i] = static_cast<unsigned>(pk - base_i) * p.lda * 4u + ca;
@@ -351,8 +371,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
             } else {
                 const int yy = y + dy, xx = x + dx;
                 ok = in_chunk & (static_cast<unsigned>(yy) < static_cast<unsigned>(p.h)) & (static_cast<unsigned>(xx) < static_cast<unsigned>(p.w));
-                areg[set][i] = buf_load(rs_a, in_chunk ? oa_run[i] : OOB);
-                breg[set][i] = buf_load(rs_b, ok ? ob_run[i] : OOB);
+                areg[set][i] = buf_load(rs_a, (PAIR == 2 ? ok : in_chunk) ? oa_run[i] : OOB);
+                breg[set][i] = buf_load(rs_b, (PAIR == 2 ? in_chunk : ok) ? ob_run[i] : OOB);
             }
             int nx = x + r16;
             const bool cx = nx >= p.w;
@@ -480,16 +500,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
             }
     }
 
-    float* outp = p.out + static_cast<int64_t>(tap) * p.m_total * p.n_total;
+    if (wave_tap >= p.taps) return;
+    float* outp = p.out + static_cast<int64_t>(wave_tap) * p.m_total * p.n_total;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + r;
+        const int n = (PAIR == 1 ? 0 : n0 + wn * 64) + j * 32 + r;
         if (n >= p.n_total) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int m = (PAIR == 2 ? 0 : m0 + wm * 64) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < p.m_total) atomicAdd(outp + static_cast<int64_t>(m) * p.n_total + n, master[i][j][e]);
             }
     }
@@ -526,7 +547,14 @@ int launch_wgrad(WgradParams& p, hipStream_t s) {
     const int bt = big ? 128 : 64;
     p.m_tiles = (p.m_total + bt - 1) / bt;
     p.n_tiles = (p.n_total + bt - 1) / bt;
-    const int64_t tiles = static_cast<int64_t>(p.m_tiles) * p.n_tiles * p.taps;
+    // 64 channels on one side of a 3x3 layer: two taps share a tile (see the kernel)
+    static const bool pairs_on = [] {   // DDPM_WGRAD_PAIR=0: diagnostic switch for A/B measurements
+        const char* e = getenv("DDPM_WGRAD_PAIR");
+        return !(e && strcmp(e, "0") == 0);
+    }();
+    const int pair = (MODE == WG_CONV3 && big && ddpm::split_math() && pairs_on) ? (p.n_total <= 64 ? 1 : (p.m_total <= 64 ? 2 : 0)) : 0;
+    p.tap_groups = pair ? (p.taps + 1) / 2 : p.taps;
+    const int64_t tiles = static_cast<int64_t>(p.m_tiles) * p.n_tiles * p.tap_groups;
     // Pixel splits: fill the chip with whole rounds of workgroups. The 128-wide tile fits 2
     // workgroups per CU (64 KB of LDS each), the 64-wide one 4: aim at two rounds of the resident
     // capacity and never exceed it by a few stragglers, which would cost a whole extra round.
@@ -548,6 +576,16 @@ int launch_wgrad(WgradParams& p, hipStream_t s) {
     p.work = static_cast<int>(tiles * splits);
     const int64_t grid = (tiles * splits + 7) / 8 * 8;
     if (int rc = clear_accumulator(p.out, static_cast<int64_t>(p.taps) * p.m_total * p.n_total, s)) return rc;
+    if constexpr (MODE == WG_CONV3) {
+        if (pair == 1) {
+            conv_wgrad_x3_kernel<MODE, 1><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
+            return ddpm::check_launch("conv_wgrad_x3_kernel");
+        }
+        if (pair == 2) {
+            conv_wgrad_x3_kernel<MODE, 2><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
+            return ddpm::check_launch("conv_wgrad_x3_kernel");
+        }
+    }
     if (big && ddpm::split_math())
         conv_wgrad_x3_kernel<MODE><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
     else if (big)

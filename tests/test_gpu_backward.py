@@ -94,7 +94,9 @@ def pack3(w, flip):
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 8, 16), (3, 28, 28, 64, 64), (2, 14, 14, 128, 256), (6, 7, 7, 512, 256), (2, 30, 30, 32, 8),
                                   (16, 28, 28, 64, 128), (6, 3, 3, 512, 512), (40, 1, 1, 128, 128), (3, 5, 3, 128, 96), (2, 2, 17, 72, 136),
-                                  (5, 33, 1, 128, 64)])
+                                  (5, 33, 1, 128, 64),
+                                  # 64 channels (or fewer) on one side, 128 or more on the other: two taps per weight-gradient tile
+                                  (4, 28, 28, 128, 64), (3, 9, 11, 64, 256), (3, 10, 7, 256, 64), (2, 5, 6, 48, 192), (2, 6, 5, 160, 40)])
 def test_conv3x3_dgrad_wgrad(case):
     B, H, W, ci, co = case
     x = rnd((B, ci, H, W), 1).requires_grad_(True)
