@@ -883,10 +883,19 @@ inline bool wide_attention() {
     return on;
 }
 
+// Shortest sequence that takes the split-bf16 kernels (DDPM_ATTN_X3_MIN_N overrides it: a diagnostic switch).
+inline int x3_min_n() {
+    static const int n = [] {
+        const char* e = getenv("DDPM_ATTN_X3_MIN_N");
+        return e ? atoi(e) : 128;
+    }();
+    return n;
+}
+
 template <int DQ>
 int launch_dq(const AttnParams& p, int batch, hipStream_t s) {
     if constexpr (DQ <= 64) {   // 128 query channels (C = 1024): only the bottleneck has them, its maps are short
-      if (ddpm::split_math() && p.n >= 128 && p.c >= 64) {
+      if (ddpm::split_math() && p.n >= x3_min_n() && p.c >= 64) {
         // 128 channels and more: the software-pipelined kernel (2-6 % faster there; 64-channel tensors are faster with two
         // query blocks per wave, and with 64 query channels the scores alone are half of a tile's MFMAs)
         if constexpr (DQ <= 32) {
