@@ -904,8 +904,10 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) {
                         const int e = 8 * ck + 4 * g4 + e4;
-                        const bool ok = (i0 + il0 + e4 < p.n) && k_ok;
-                        const float pe = ok ? __builtin_amdgcn_exp2f((s[e] - l4[e4]) * 1.4426950408889634f) : 0.f;
+                        // No masks here. A query past the end has zero rows of Q and dO and zero lse and D (range-checked
+                        // loads): P = 1 and dS = 0 there, and its column of dO^T / Q^T is zero. A key past the end only
+                        // ever affects ITS OWN output column (lane = key is the B operand's column), which is not stored.
+                        const float pe = __builtin_amdgcn_exp2f((s[e] - l4[e4]) * 1.4426950408889634f);
                         pv[4 * g4 + e4] = pe;
                         dsv[4 * g4 + e4] = pe * (dp[e] - d4[e4]);
                     }
@@ -1121,14 +1123,19 @@ __global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(
             u32x4 ds[2][3];
 #pragma unroll
             for (int ck = 0; ck < 2; ++ck) {
+                // Only keys past the end need a mask (their rows of K^T meet dS in the product below; a probability that
+                // overflowed there would turn 0 * inf into NaN), and only the last tile has any: one uniform branch. A
+                // query past the end has zero Q, dO, lse and D, hence dS = 0.
                 float dsv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int e = 8 * ck + j;
-                    const bool ok = q_ok && (j0 + rowmap(e, h) < p.n);
-                    const float pe = ok ? __builtin_amdgcn_exp2f((s[e] - lse_i) * 1.4426950408889634f) : 0.f;
-                    dsv[j] = pe * (dp[e] - d_i);
+                for (int j = 0; j < 8; ++j) dsv[j] = __builtin_amdgcn_exp2f((s[8 * ck + j] - lse_i) * 1.4426950408889634f);
+                if (j0 + 32 > p.n) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j0 + rowmap(8 * ck + j, h) >= p.n) dsv[j] = 0.f;
                 }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsv[j] *= dp[8 * ck + j] - d_i;
                 split8(dsv, ds[ck][0], ds[ck][1], ds[ck][2]);
             }
             {   // dQ^T += K^T dS^T, the two 16-key chunks side by side

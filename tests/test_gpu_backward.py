@@ -304,3 +304,36 @@ def test_attention_bwd(case):
     assert_close(got[..., 2 * dqp:], v.grad, TOL, f"dv {case}")
     assert torch.all(got[..., dq:dqp] == 0) and torch.all(got[..., dqp + dq:2 * dqp] == 0)
     assert abs(dgamma.item() - gamma.grad.item()) <= 1e-4 * max(1.0, abs(gamma.grad.item()))
+
+
+@pytest.mark.parametrize("case", [(2, 200, 64, 8), (1, 170, 128, 16), (2, 136, 256, 32)])
+def test_attention_bwd_very_negative_scores_ragged(case):
+    """Every score is around -150 and the sequence does not fill its last 32-row tile: exp(0 - lse) of a key row past
+    the end overflows to infinity. The kernels do not mask such rows where they only reach their own (unstored)
+    output column, and must mask them where they meet real data; no NaN may come out."""
+    B, N, c, dq = case
+    base = torch.ones(dq) * (150.0 / dq) ** 0.5
+    q = (base + 0.05 * rnd((B, N, dq), 2)).requires_grad_(True)
+    k = (-base + 0.05 * rnd((B, N, dq), 3)).requires_grad_(True)
+    v = rnd((B, N, c), 4).requires_grad_(True)
+    x = rnd((B, N, c), 1)
+    gamma = torch.tensor([0.8], dtype=torch.float64, requires_grad=True)
+    sc = torch.bmm(q.double(), k.double().transpose(1, 2))
+    assert sc.max() < -120
+    y = gamma * torch.bmm(torch.softmax(sc, dim=-1), v.double()) + x.double()
+    dy = rnd((B, N, c), 5)
+    y.backward(dy.double())
+    qkv = torch.cat([q.detach(), k.detach(), v.detach()], -1)
+    out, raw, lse = (torch.empty((B, N, c), device="cuda"), torch.empty((B, N, c), device="cuda"), torch.empty((B, N), device="cuda"))
+    qd, xd, gd = qkv.cuda(), x.cuda(), gamma.detach().float().cuda()
+    call("ddpm_attention_fwd", P(qd), P(xd), c, P(gd), P(out), c, P(raw), P(lse), None, B, N, c, dq, stream())
+    assert_close(out.cpu(), y.detach(), TOL, f"forward {case}")
+    dqkv = torch.full((B, N, 2 * dq + c), float("nan"), device="cuda")
+    dgamma = torch.empty(1, device="cuda")
+    ws, es = torch.empty(4096, dtype=torch.float64, device="cuda"), torch.empty((B, N), device="cuda")
+    call("ddpm_attention_bwd", P(qd), P(dy.cuda()), c, P(raw), P(lse), P(gd), P(ws), P(es), P(dqkv), P(dgamma), B, N, c, dq, stream())
+    got = dqkv.cpu()
+    assert torch.isfinite(got).all()
+    assert_close(got[..., :dq], q.grad, TOL, f"dq {case}")
+    assert_close(got[..., dq:2 * dq], k.grad, TOL, f"dk {case}")
+    assert_close(got[..., 2 * dq:], v.grad, TOL, f"dv {case}")
