@@ -1,7 +1,7 @@
 // The two thin layers at the edges of the UNet, which are not GEMM-shaped enough for the matrix
 // cores: the first 3x3 conv (1 or 3 input channels, NCHW image in, NHWC out) and the final 1x1
 // conv (NHWC in, 1 or 3 channels, NCHW out). Both are memory-bound.
-#include "common.h"
+#include "conv_common.h"
 #include "process_math.h"
 
 using ddpm::as_stream;
@@ -10,13 +10,11 @@ namespace {
 
 constexpr int kMaxLdsFloats = 12288;  // 48 KB of weights staged per workgroup
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == DDPM_ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == DDPM_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    return v;
-}
-
-// One thread = one pixel x 4 consecutive output channels. Weights sit in LDS as [ci*9+tap][cout].
+// One thread = one pixel x 4 consecutive output channels. Weights sit in LDS as [ci*9+tap][cout]. The kernel writes
+// 16 bytes per thread and reads next to nothing, so what it costs besides the store stream is index arithmetic and the
+// activation: when the workgroup's 256 threads cover whole pixels (cout / 4 divides 256) a thread keeps its channel
+// quad for the whole launch (scale, shift in registers, no division by the channel count) and walks pixels with 32-bit
+// arithmetic; GELU is the polynomial-erf form the matrix kernels use in their epilogues.
 __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ residual_unused, const float* __restrict__ temb,
@@ -29,15 +27,37 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restr
         sw[i] = w[static_cast<int64_t>(co) * kt + k];
     }
     __syncthreads();
-    const int c4n = cout >> 2;
-    const int64_t total = static_cast<int64_t>(batch) * h * wd * c4n;
-    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
-         idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const int c4 = static_cast<int>(idx % c4n);
-        const int64_t pix = idx / c4n;
-        const int xx = static_cast<int>(pix % wd);
-        const int yy = static_cast<int>((pix / wd) % h);
-        const int b = static_cast<int>(pix / (static_cast<int64_t>(wd) * h));
+    const unsigned c4n = static_cast<unsigned>(cout) >> 2;
+    const unsigned pixels = static_cast<unsigned>(batch) * h * wd;      // < 2^31, checked by the caller
+    const bool whole = 256u % c4n == 0u;
+    // pixel and channel quad of this thread: fixed quad when a workgroup covers whole pixels, else re-derived per step
+    const unsigned ppb = whole ? 256u / c4n : 0u;
+    unsigned c4 = whole ? threadIdx.x % c4n : 0u;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    auto load_affine = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sc[e] = scale ? scale[c4 * 4 + e] : 1.0f;
+            sh[e] = shift ? shift[c4 * 4 + e] : 0.0f;
+        }
+    };
+    if (whole) load_affine();
+    const uint64_t total = static_cast<uint64_t>(pixels) * c4n;
+    uint64_t idx = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
+    unsigned pix = whole ? blockIdx.x * ppb + threadIdx.x / c4n : 0u;
+    for (;;) {
+        if (whole) {
+            if (pix >= pixels) break;
+        } else {
+            if (idx >= total) break;
+            c4 = static_cast<unsigned>(idx % c4n);
+            pix = static_cast<unsigned>(idx / c4n);
+            load_affine();
+        }
+        const unsigned row = pix / static_cast<unsigned>(wd);
+        const int xx = static_cast<int>(pix - row * wd);
+        const unsigned b = row / static_cast<unsigned>(h);
+        const int yy = static_cast<int>(row - b * h);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int ci = 0; ci < cin; ++ci) {
             const float* plane = x + (static_cast<int64_t>(b) * cin + ci) * h * wd;
@@ -51,14 +71,21 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restr
         }
         float r[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int n = c4 * 4 + e;
-            float v = r[e] * (scale ? scale[n] : 1.0f) + (shift ? shift[n] : 0.0f);
-            v = act_apply(v, act);
-            if (temb) v += temb[static_cast<int64_t>(b) * cout + n];
-            r[e] = v;
+        for (int e = 0; e < 4; ++e) r[e] = r[e] * sc[e] + sh[e];
+        if (act == DDPM_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = ddpm::conv::apply_act_fast(r[e], DDPM_ACT_GELU);
+        } else if (act == DDPM_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : 0.f;
         }
-        *reinterpret_cast<float4*>(out + pix * ldo + c4 * 4) = make_float4(r[0], r[1], r[2], r[3]);
+        if (temb) {
+            const float4 tv = *reinterpret_cast<const float4*>(temb + static_cast<int64_t>(b) * cout + c4 * 4);
+            r[0] += tv.x; r[1] += tv.y; r[2] += tv.z; r[3] += tv.w;
+        }
+        *reinterpret_cast<float4*>(out + static_cast<int64_t>(pix) * ldo + c4 * 4) = make_float4(r[0], r[1], r[2], r[3]);
+        if (whole) pix += gridDim.x * ppb;
+        else idx += static_cast<uint64_t>(gridDim.x) * 256u;
     }
 }
 
@@ -246,6 +273,8 @@ extern "C" int ddpm_conv3x3_first_fwd(const float* x_nchw, const float* w, const
     DDPM_REQUIRE(cin * 9 * cout <= kMaxLdsFloats);
     DDPM_REQUIRE(!ep->residual && (!ep->scale || ep->shift));
     DDPM_REQUIRE(act >= DDPM_ACT_NONE && act <= DDPM_ACT_GELU);
+    DDPM_REQUIRE(static_cast<int64_t>(batch) * h * w_ < (1ll << 31));
+    DDPM_REQUIRE(!ep->temb || ddpm::aligned16(ep->temb));
     const int64_t total = static_cast<int64_t>(batch) * h * w_ * (cout / 4);
     int64_t grid = (total + 255) / 256;
     if (grid > 256 * 16) grid = 256 * 16;
