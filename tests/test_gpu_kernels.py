@@ -297,6 +297,9 @@ def test_pool_skip_and_add_temb(case):
                                   (1, 784, 128, 16), (3, 33, 256, 32),
                                   # N = 4096 (64x64 feature maps): the split-bf16 kernel at its longest sequence
                                   (1, 4096, 64, 8), (1, 4096, 128, 16),
+                                  # edges of the software-pipelined kernel (C >= 128, N >= 128): one, two and three key tiles, a
+                                  # ragged last tile, a last channel block that is partly empty, the widest query depth it takes
+                                  (2, 128, 128, 16), (3, 129, 128, 16), (2, 160, 256, 32), (2, 161, 192, 32), (1, 200, 160, 8), (2, 95 + 33, 320, 32),
                                   # 128 query channels: the bottleneck of a base_channels = 128 network (C = 1024)
                                   (2, 64, 1024, 128), (2, 49, 1024, 128), (1, 256, 1024, 128), (3, 16, 1024, 128),
                                   # small maps: one workgroup per sample (forward up to 32 pixels, backward up to 49)
