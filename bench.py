@@ -205,6 +205,7 @@ class Job:
         betas = pkg.BetaScheduler(T_FULL, device=dev).get_schedule("linear")
         self.dm = dm = pkg.make_diffusion_class(wl["variant"])(model, betas, T_FULL)
         gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        torch.manual_seed(4321 + rank)      # build_model seeds every rank alike (same weights); the noise of the steps must differ per rank
         self.sampling = workload.startswith("sample")
         self.state = state = {}
         self.reducer = None

@@ -73,11 +73,38 @@ def average_gradients(params, group=None):
         off += n
 
 
+_rng_checked = False
+
+
+def decorrelate_rng(device, group=None):
+    """Make sure no two ranks draw the same noise. Scripts usually seed every process alike (torch.manual_seed(0)), and
+    ranks that then draw their own x_T and z would all produce the SAME samples. Once per process: the ranks compare
+    the seeds of the generator that torch.randn on `device` uses; if any two agree, every rank reseeds that generator
+    with seed + rank (rank 0 keeps the sequence a single process would have had)."""
+    global _rng_checked
+    world, rank = _world(group)
+    if _rng_checked or world == 1:
+        return
+    _rng_checked = True
+    dev = torch.device(device)
+    seed = torch.cuda.initial_seed() if dev.type == "cuda" else torch.initial_seed()
+    seeds = [None] * world
+    dist.all_gather_object(seeds, int(seed), group=group)
+    if len(set(seeds)) < world:
+        new = (int(seed) + rank) % (1 << 63)
+        if dev.type == "cuda":
+            with torch.cuda.device(dev):
+                torch.cuda.manual_seed(new)
+        else:
+            torch.default_generator.manual_seed(new)
+
+
 def sample_sharded(diffusion, x_shape, device, gather=True, noise=None, group=None, **sample_kwargs):
     """Run diffusion.sample on this rank's slice of the batch axis.
 
     noise: optional (x_T, [z ...]) for the WHOLE batch; each rank injects its slice, so that the
-    sharded result equals the single-process one sample for sample.
+    sharded result equals the single-process one sample for sample. Without it every rank draws its
+    own noise, from generators that decorrelate_rng has made distinct.
     Returns the reference's stage list; with gather=True every rank gets the whole batch
     (concatenated in rank order), otherwise only its own slice.
     """
@@ -86,6 +113,8 @@ def sample_sharded(diffusion, x_shape, device, gather=True, noise=None, group=No
     local_shape = (hi - lo,) + tuple(x_shape[1:])
     if noise is not None:
         sample_kwargs["noise"] = (noise[0][lo:hi], [z[lo:hi] for z in noise[1]])
+    else:
+        decorrelate_rng(device, group)
     stages = diffusion.sample(local_shape, device, **sample_kwargs) if hi > lo else []
     if world == 1 or not gather:
         return stages

@@ -25,6 +25,8 @@ class ToyDiffusion:
     """Deterministic stand-in with the reference's sample() contract (list of (cpu tensor, t))."""
 
     def sample(self, x_shape, device="cpu", noise=None):
+        if noise is None:                       # own noise from torch's default generator, as the reference's sample() draws it
+            noise = (torch.randn(x_shape), [torch.randn(x_shape) for _ in range(3)])
         x = noise[0].clone()
         stages = []
         for i, z in enumerate(noise[1]):
@@ -116,6 +118,14 @@ def _worker(rank, world, port, tmp):
         mine = parallel.sample_sharded(ToyDiffusion(), shape, "cpu", gather=False, noise=noise)
         lo, hi = parallel.shard_range(5, world, rank)
         assert torch.equal(mine[-1][0], whole[-1][0][lo:hi])
+        # own noise: every rank was seeded alike above (torch.manual_seed(0)), yet the shards must not repeat each other
+        torch.manual_seed(0)
+        own = parallel.sample_sharded(ToyDiffusion(), (4, 1, 4, 4), "cpu")
+        final = own[-1][0]
+        assert final.shape[0] == 4 and not torch.equal(final[:2], final[2:])
+        torch.manual_seed(0)
+        expect_rank0 = ToyDiffusion().sample((2, 1, 4, 4))[-1][0]
+        assert torch.equal(final[:2], expect_rank0)                    # rank 0 keeps the single-process sequence
         open(os.path.join(tmp, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()
