@@ -57,6 +57,9 @@ WORKLOADS = {
                         "batch 4096 sharded over 8 GPUs (512 per GPU)", variant=3, cin=1, hw=32, batch=512, labels=True,
                    metric="sampled images/sec (full T-step loop)", unit="images/s"),
     # the remaining configs: parity-test shapes, measurable here on request (never the default line)
+    "sample_c1": dict(name="configs[0]: first-iteration UNet (1,1,64,128), 1x28x28, batch 64, full T=1000 ancestral sampling with the "
+                           "linear schedule (the case the reference runs on the CPU)", variant=1, cin=1, hw=28, batch=64, labels=False,
+                      metric="sampled images/sec (full T-step loop)", unit="images/s"),
     "train_color": dict(name="configs[3]: third-iteration UNet (3,3,64,128), colour 3x32x32, batch 256 per GPU training step, "
                              "data-parallel gradient all-reduce", variant=3, cin=3, hw=32, batch=256, labels=False,
                         metric="train samples/sec", unit="samples/s"),
