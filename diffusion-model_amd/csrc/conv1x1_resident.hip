@@ -258,6 +258,276 @@ int launch_one(const GemmParams& p, int grid, int lds, hipStream_t s) {
     return check_launch("conv1x1_resident_kernel");
 }
 
+// ---- the same kernel for weight matrices that do not fit LDS (256 and 512 channels) ----------------------------
+// The columns are cut into tiles of at most six 32-column blocks (grid.y; the workgroups of one row range run on one
+// XCD and share the activations in its L2) and K into slabs of four 16-channel chunks. A slab of the tile's weights
+// (at most 72 KiB) sits in one of two LDS buffers; all 512 threads request the next slab at the top of a slab, store it
+// into the other buffer behind the slab's four steps, and one barrier per slab hands it over. A slab is four steps,
+// which is also the depth of the activation prefetch ring and the fold interval. Same product order and folds as the
+// resident kernel and the generic one: the three agree bit for bit.
+constexpr int kSlabChunks = 4;
+
+template <int NBW>
+__device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned char* wsm, int wr, int nb_in_tile, int nb_first, int nbt,
+                                               int g_begin, int g_end, int lane, const __amdgpu_buffer_rsrc_t rs_w, unsigned tile_off) {
+    const int tid = threadIdx.x;
+    const int r = lane & 31, h = lane >> 5;
+    const int kc16 = p.kc16, nslab = kc16 / kSlabChunks;
+    const int groups = g_end - g_begin;
+    const int max_tile = (groups + 3) >> 2;                    // row groups of the busiest wave: every wave runs that many rounds
+    const int ntile = groups > wr ? (groups - wr + 3) >> 2 : 0;
+    const unsigned slab_bytes = static_cast<unsigned>(kSlabChunks * nbt) * 3072u;
+    const unsigned run_bytes = static_cast<unsigned>(nbt) * 3072u;          // one chunk of the tile: contiguous in the packed weights
+    const unsigned chunk_stride_g = static_cast<unsigned>(p.nbp) * 3072u;
+
+    // this thread's pieces of a slab: 16-byte piece i of chunk c of the slab comes from global offset
+    // (slab * 4 + c) * chunk_stride_g + tile_off + i * 16
+    constexpr int kPieces = (kSlabChunks * 6 * 3072 / 16 + kThreads - 1) / kThreads;   // 9 for six blocks
+    u32x4 wreg[kPieces];
+    auto load_slab = [&](int slab) {
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const unsigned q = (tid + i * kThreads) * 16u;                 // byte offset inside the slab's LDS image
+            const unsigned c = q / run_bytes, o = q - c * run_bytes;
+            const unsigned goff = (static_cast<unsigned>(slab) * kSlabChunks + c) * chunk_stride_g + tile_off + o;
+            // columns past the last block of the matrix (a ragged last tile) lie in the next chunk's run: read zeros instead
+            const bool ok = q < slab_bytes && tile_off + o < chunk_stride_g;
+            wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, ok ? goff : OOB, 0, 0);
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const unsigned q = (tid + i * kThreads) * 16u;
+            if (q < slab_bytes) *reinterpret_cast<u32x4*>(wsm + buf * slab_bytes + q) = wreg[i];
+        }
+    };
+
+    const long long row0 = static_cast<long long>(g_begin) * 32;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.src1 + row0 * p.ld1, (p.src1_pixels - row0) * p.ld1 * 4ll);
+    const unsigned ld4 = static_cast<unsigned>(p.ld1) * 4u;
+    int lt = 0, lk = 0;
+    auto load_a = [&](f32x4 (&v)[2]) {
+        const int row = (wr + 4 * lt) * 32 + r;
+        const bool live = lt < ntile && row0 + row < p.m_total;
+        const int c = lk * XK + h * 8;
+        const unsigned base = static_cast<unsigned>(row) * ld4 + static_cast<unsigned>(c) * 4u;
+        v[0] = buf_load(rs_a, (live && c < p.ctot) ? base : OOB);
+        v[1] = buf_load(rs_a, (live && c + 4 < p.ctot) ? base + 16u : OOB);
+        if (++lk == kc16) {
+            lk = 0;
+            ++lt;
+        }
+    };
+
+    bf16x8 bw[NBW][3], bw0[2][NBW];
+    const unsigned lane_off = static_cast<unsigned>(nb_in_tile) * 3072u + lane * 16u;
+    const unsigned char* wcur = wsm;            // current slab buffer + this wave's blocks
+    auto read_b = [&](int c, int pl) {
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) bw[j][pl] = *reinterpret_cast<const bf16x8*>(wcur + c * run_bytes + j * 3072u + pl * 1024u);
+    };
+    auto read_b0 = [&](bf16x8 (&dst)[NBW], int c) {
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(wcur + c * run_bytes + j * 3072u);
+    };
+
+    f32x4 ra[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_a(ra[i]);
+
+    f32x16 acc[NBW], master[NBW];
+    auto zero = [](f32x16& v) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = 0.f;
+    };
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        zero(acc[j]);
+        zero(master[j]);
+    }
+
+    // step c (0..3) of the current slab
+    auto step = [&](int c, f32x4 (&raw)[2], bf16x8 (&b0cur)[NBW], bf16x8 (&b0next)[NBW]) {
+        bf16x8 a0, a1, a2;
+        split8(raw[0], raw[1], a0, a1, a2);
+        load_a(raw);
+        auto term = [&](const bf16x8& a, int pb) {
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {
+                const bf16x8& b = pb == 0 ? b0cur[j] : bw[j][pb];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            }
+        };
+        const bool more = c + 1 < kSlabChunks;      // the next step's fragments are in this slab
+        if (more) read_b0(b0next, c + 1);
+        term(a2, 0);
+        term(a0, 2);
+        if (more) read_b(c + 1, 2);
+        term(a1, 1);
+        term(a1, 0);
+        term(a0, 1);
+        if (more) read_b(c + 1, 1);
+        term(a0, 0);
+    };
+
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+
+    const int rounds = max_tile * nslab;
+    int t = 0, sl = 0;                               // row-group round and slab of this iteration
+    for (int q = 0; q < rounds; ++q) {
+        const int buf = q & 1;
+        const bool more = q + 1 < rounds;
+        const int sl_next = sl + 1 == nslab ? 0 : sl + 1;
+        if (more) load_slab(sl_next);
+        if (t < ntile) {
+            wcur = wsm + buf * slab_bytes + lane_off;
+            read_b0(bw0[0], 0);
+            read_b(0, 1);
+            read_b(0, 2);
+            step(0, ra[0], bw0[0], bw0[1]);
+            step(1, ra[1], bw0[1], bw0[0]);
+            step(2, ra[2], bw0[0], bw0[1]);
+            step(3, ra[3], bw0[1], bw0[0]);
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {          // a slab is one fold interval
+                master[j] += acc[j];
+                zero(acc[j]);
+            }
+            if (sl + 1 == nslab) {
+                // ---- epilogue of row group g: bias / folded BatchNorm, residual, activation ----------------
+                const int g = __builtin_amdgcn_readfirstlane(g_begin + wr + 4 * t);
+                const long long m0 = static_cast<long long>(g) * 32;
+                const long long rows_left = p.m_total - m0;
+                const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out + m0 * p.ldo, rows_left * p.ldo * 4ll);
+                const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(p.residual ? p.residual + m0 * p.ldr : p.out, p.residual ? rows_left * p.ldr * 4ll : 0ll);
+                const unsigned ldo4 = static_cast<unsigned>(p.ldo) * 4u, ldr4 = static_cast<unsigned>(p.ldr) * 4u;
+                int hq = 4 * h;
+                asm volatile("" : "+v"(hq));   // keeps the per-element offsets below from being hoisted out of the loop (registers)
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) {
+                    const int n = (nb_first + j) * 32 + r;
+                    if (n < p.n_total) {
+                        const float sc = p.scale ? p.scale[n] : 1.0f;
+                        const float sh = p.shift ? p.shift[n] : 0.0f;
+                        const unsigned n4 = static_cast<unsigned>(n) * 4u;
+                        float v[16];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = master[j][e] * sc + sh;
+                        if (p.residual) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const unsigned row = static_cast<unsigned>((e & 3) + 8 * (e >> 2) + hq);
+                                v[e] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, row * ldr4 + n4, 0, 0));
+                            }
+                        }
+                        if (p.act == DDPM_ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        } else if (p.act == DDPM_ACT_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) v[e] = apply_act_fast(v[e], DDPM_ACT_GELU);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const unsigned row = static_cast<unsigned>((e & 3) + 8 * (e >> 2) + hq);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, row * ldo4 + n4, 0, 0);
+                        }
+                    }
+                    zero(master[j]);
+                }
+            }
+        }
+        if (more) store_slab(buf ^ 1);
+        __syncthreads();
+        if (++sl == nslab) {
+            sl = 0;
+            ++t;
+        }
+    }
+}
+
+template <int NB0, int NB1>
+__global__ __launch_bounds__(kThreads, 1) void conv1x1_slab_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];   // [2][chunk of the slab][block of the tile][plane][lane][16 B]
+    constexpr int NBT = NB0 + NB1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 3, wn = wave >> 2;
+    // workgroups that share rows (the column tiles of one row range) take consecutive numbers on ONE XCD
+    const int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
+        id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+    }
+    const int ct = id % p.n_tiles;
+    const int rw = id / p.n_tiles;
+    const int g_begin = __builtin_amdgcn_readfirstlane(rw * p.gpb);
+    const int g_end = __builtin_amdgcn_readfirstlane(min(p.groups_total, g_begin + p.gpb));
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+    const unsigned tile_off = static_cast<unsigned>(ct * NBT) * 3072u;
+    if (g_begin >= g_end) return;       // (whole workgroup: no barrier is skipped by part of it)
+    if (wn == 0) slab_wave_body<NB0>(p, wsm, wr, 0, ct * NBT, NBT, g_begin, g_end, lane, rs_w, tile_off);
+    else slab_wave_body<(NB1 > 0 ? NB1 : 1)>(p, wsm, wr, NB0, ct * NBT + NB0, NBT, g_begin, g_end, lane, rs_w, tile_off);
+}
+
+template <int NB0, int NB1>
+int launch_slab(const GemmParams& p, int grid, int lds, hipStream_t s) {
+    constexpr int kMax = 2 * kSlabChunks * 6 * 3072;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_slab_kernel<NB0, NB1>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+    if (attr != hipSuccess) {
+        set_error("conv1x1_slab_kernel: cannot reserve %d bytes of LDS: %s", kMax, hipGetErrorString(attr));
+        return DDPM_E_LAUNCH;
+    }
+    conv1x1_slab_kernel<NB0, NB1><<<dim3(grid), dim3(kThreads), lds, s>>>(p);
+    return check_launch("conv1x1_slab_kernel");
+}
+
+// Returns 1 when the shape is not this kernel's (the caller goes on to the generic one).
+int launch_conv1x1_slab(GemmParams& p, hipStream_t s) {
+    if (p.c2 > 0 || p.temb || p.m_total < 16384 || (p.ctot % (XK * kSlabChunks)) != 0) return 1;
+    if (static_cast<long long>(p.m_total) * p.ld1 * 4ll >= 0x7fffffffll) return 1;
+    p.kc16 = p.ctot / XK;
+    p.nbp = (p.n_total + 31) / 32;
+    const long long wb = 3072ll * p.nbp * p.kc16;
+    if (wb >= 0x7fffffffll) return 1;
+    p.w_bytes = static_cast<unsigned>(wb);
+    p.groups_total = (p.m_total + 31) / 32;
+    // One workgroup per CU: 256 of them, shared between the column tiles; a wave takes every fourth row group of its
+    // workgroup. The busiest SIMD issues (rounds of row groups) x (blocks per tile) MFMA sets, and every round reads its
+    // rows once more (the "+ 1"): the fewest tiles that hold six blocks each, or one tile more when that is cheaper
+    // (16 blocks: four tiles of four instead of three of six, which would leave a quarter of the CUs idle).
+    int best_nt = 0, best_cost = 0, nbt = 0, gpb = 0;
+    for (int nt = (p.nbp + 5) / 6; nt <= (p.nbp + 5) / 6 + 1 && nt * 2 <= p.nbp; ++nt) {
+        const int b = (p.nbp + nt - 1) / nt;
+        const int row_wgs = 256 / nt;
+        const int g = ((p.groups_total + row_wgs - 1) / row_wgs + 3) & ~3;     // whole rounds: the four row waves stay level
+        const int cost = (g / 4) * (b + 1);
+        if (best_nt == 0 || cost < best_cost) {
+            best_nt = nt;
+            best_cost = cost;
+            nbt = b;
+            gpb = g;
+        }
+    }
+    if (best_nt == 0) return 1;
+    p.n_tiles = best_nt;
+    p.gpb = gpb;
+    const int grid = ((p.groups_total + gpb - 1) / gpb) * p.n_tiles;
+    const int lds = 2 * kSlabChunks * nbt * 3072;
+    switch (nbt) {
+        case 2: return launch_slab<1, 1>(p, grid, lds, s);
+        case 3: return launch_slab<2, 1>(p, grid, lds, s);
+        case 4: return launch_slab<2, 2>(p, grid, lds, s);
+        case 5: return launch_slab<3, 2>(p, grid, lds, s);
+        default: return launch_slab<3, 3>(p, grid, lds, s);
+    }
+}
+
 }  // namespace
 
 int launch_conv1x1_resident(GemmParams& p, hipStream_t s) {
@@ -266,9 +536,8 @@ int launch_conv1x1_resident(GemmParams& p, hipStream_t s) {
     if (p.c2 > 0 || p.temb || p.m_total < 16384 || (p.ctot & 3) != 0) return 1;
     p.kc16 = (p.ctot + XK - 1) / XK;
     p.nbp = (p.n_total + 31) / 32;
-    if (p.nbp > 6) return 1;
     const long long wb = 3072ll * p.nbp * p.kc16;
-    if (wb > kMaxWeightLds) return 1;
+    if (p.nbp > 6 || wb > kMaxWeightLds) return launch_conv1x1_slab(p, s);
     if (static_cast<long long>(p.m_total) * p.ld1 * 4ll >= 0x7fffffffll) return 1;   // 32-bit offsets inside one descriptor
     p.w_bytes = static_cast<unsigned>(wb);
     p.groups_total = (p.m_total + 31) / 32;

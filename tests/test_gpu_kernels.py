@@ -199,7 +199,10 @@ def test_conv1x1(case):
 
 
 @pytest.mark.parametrize("case", [(32, 784, 128, 160, 0), (24, 1024, 64, 80, 0), (21, 784, 160, 128, 1), (17, 1024, 80, 64, 1), (40, 441, 128, 72, 2),
-                                  (33, 500, 68, 192, 0), (20, 900, 128, 33, 2)])
+                                  (33, 500, 68, 192, 0), (20, 900, 128, 33, 2),
+                                  # weights too large for LDS: column tiles and K slabs (ragged last tile, a single slab, residual, GELU)
+                                  (40, 441, 256, 320, 0), (36, 500, 512, 640, 1), (33, 500, 256, 256, 2), (34, 490, 320, 200, 0),
+                                  (35, 480, 64, 448, 2), (20, 900, 192, 224, 1)])
 def test_conv1x1_many_rows(case):
     """Shapes of the attention projections at full resolution (rows >= 16384, weights small enough to stay in LDS): the
     kernel with resident weights. mode 0: bias; 1: the data-gradient form (no bias, residual add, strided residual);
