@@ -9,3 +9,4 @@ timeout -s KILL 90 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LD
 timeout -s KILL 90 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_WAVES -d $out/b -o b -- python tools/microbench.py attn $shape 3 > $out/b.log 2>&1 || { tail -5 $out/b.log; exit 1; }
 timeout -s KILL 90 rocprofv3 --pmc GRBM_GUI_ACTIVE -d $out/c -o c -- python tools/microbench.py attn $shape 3 > $out/c.log 2>&1 || { tail -5 $out/c.log; exit 1; }
 for f in $out/a/*.db $out/b/*.db $out/c/*.db; do python tools/pmc_summary.py $f | grep -A9 "attention_fwd"; done
+rm -f $out/*/*.db

@@ -19,6 +19,7 @@ f = per_kernel(glob.glob(sys.argv[1] + "/*.db")[0], "FETCH_SIZE")
 for k in sorted(f, key=lambda k: -f[k][0])[:3]:
     print(f"{sys.argv[2]:10s} raw FETCH_SIZE {f[k][0] * 1024 / f[k][1] / 1e6:9.1f} MB per dispatch ({f[k][1]} dispatches)  {k[:90]}")
 PY
+  rm -f $out/$tag/*.db
 }
 run step step 67108864 5 || exit 1
 run conv3x3 conv3x3 2048 32 32 64 64 3 || exit 1
