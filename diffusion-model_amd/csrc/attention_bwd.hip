@@ -34,25 +34,35 @@ struct BwdParams {
     int n, c, dqp, lq, ldd;
 };
 
-// E[b][i] = dY[i].O[i]; partial sums of E per workgroup for dgamma
+// E[b][i] = dY[i].O[i]; partial sums of E per workgroup for dgamma. A row takes c / 4 lanes (16 bytes each) up to a
+// whole wave, so a wave works on 64 / (c / 4) rows at once: with 128 channels one row per wave would leave half of
+// the lanes without a load.
 __global__ __launch_bounds__(256) void attn_bwd_pre_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ o, int c,
                                                             int64_t rows, float* __restrict__ e, double* __restrict__ partial) {
     __shared__ double red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lpr = 64;                                   // lanes per row: the power of two that covers c / 4, at most 64
+    while (lpr > 1 && (lpr >> 1) * 4 >= c) lpr >>= 1;
+    const int rpw = 64 / lpr;                       // rows per wave
+    const int sub = lane & (lpr - 1), rw = lane / lpr;
     double acc = 0.0;
-    for (int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + wave; r < rows; r += static_cast<int64_t>(gridDim.x) * 4) {
+    for (int64_t r0 = (static_cast<int64_t>(blockIdx.x) * 4 + wave) * rpw; r0 < rows; r0 += static_cast<int64_t>(gridDim.x) * 4 * rpw) {
+        const int64_t r = r0 + rw;
         float s = 0.f;
-        for (int ch = lane * 4; ch < c; ch += 256) {
-            const float4 a = *reinterpret_cast<const float4*>(dy + r * ldd + ch);
-            const float4 b = *reinterpret_cast<const float4*>(o + r * c + ch);
-            s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        if (r < rows) {
+            for (int ch = sub * 4; ch < c; ch += lpr * 4) {
+                const float4 a = *reinterpret_cast<const float4*>(dy + r * ldd + ch);
+                const float4 b = *reinterpret_cast<const float4*>(o + r * c + ch);
+                s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            }
         }
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) {
+        for (int off = lpr >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (sub == 0 && r < rows) {
             e[r] = s;
             acc += s;
         }
     }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);      // fixed tree: the sum does not depend on timing
     if (lane == 0) red[wave] = acc;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
