@@ -55,6 +55,7 @@ _SIGNATURES = {
     "ddpm_conv1x1_fwd": [C.POINTER(ConvDesc), P, P, P, C.POINTER(Epilogue), P, P],
     "ddpm_convT2x2_fwd": [C.POINTER(ConvDesc), P, P, C.POINTER(Epilogue), P, P],
     "ddpm_pack_conv3x3": [P, I32, I32, I32, P, P],
+    "ddpm_pack_conv3x3_batch": [I32, P, P, P, P, P, P],
     "ddpm_pack_convT2x2": [P, I32, I32, P, P],
     "ddpm_pack_conv1x1": [P, I32, I32, I32, P, P],
     "ddpm_pack_qkv": [P, P, P, P, P, P, I32, I32, I32, P, P, P, P],

@@ -892,6 +892,58 @@ __global__ void pack_qkv_kernel(const QkvPack a) {
     }
 }
 
+SplitPack make_split_pack(const float* w, float* out, int taps, int rows, int cin, int nq, long long base, long long st,
+                          long long sq, long long sn, long long sc) {
+    SplitPack a;
+    a.w = w;
+    a.out = reinterpret_cast<unsigned short*>(out);
+    a.taps = taps;
+    a.rows = rows;
+    a.cin = cin;
+    a.kc16 = (cin + 15) / 16;
+    a.nbp = (rows + 31) / 32;
+    a.nq = nq;
+    a.base = base;
+    a.st = st;
+    a.sq = sq;
+    a.sn = sn;
+    a.sc = sc;
+    return a;
+}
+
+// Several weight tensors in one launch (blockIdx.y picks the tensor): a training step repacks every convolution weight
+// after the optimizer has changed it, and forty launches of a few microseconds each cost more than the packing.
+constexpr int kPackBatch = 16;
+struct SplitPackBatch {
+    SplitPack item[kPackBatch];
+};
+__global__ void pack_split_batch_kernel(const SplitPackBatch b) {
+    const SplitPack& a = b.item[blockIdx.y];
+    const int64_t total = static_cast<int64_t>(a.taps) * a.kc16 * a.nbp * 512;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int j = static_cast<int>(i & 7);
+        const int fl = static_cast<int>((i >> 3) & 63);
+        int64_t rest = i >> 9;
+        const int nb = static_cast<int>(rest % a.nbp);
+        rest /= a.nbp;
+        const int kc = static_cast<int>(rest % a.kc16);
+        const int tap = static_cast<int>(rest / a.kc16);
+        const int n = nb * 32 + (fl & 31);
+        const int c = kc * 16 + (fl >> 5) * 8 + j;
+        float v = 0.f;
+        if (c < a.cin && n < a.rows) v = a.w[a.base + tap * a.st + (n / a.nq) * a.sq + (n % a.nq) * a.sn + c * a.sc];
+        const unsigned u = __float_as_uint(v);
+        const float r1 = v - __uint_as_float(u & 0xffff0000u);
+        const unsigned m = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(m & 0xffff0000u);
+        unsigned short* o = a.out + (i >> 9) * 1536 + fl * 8 + j;
+        o[0] = static_cast<unsigned short>(u >> 16);
+        o[512] = static_cast<unsigned short>(m >> 16);
+        o[1024] = static_cast<unsigned short>(__float_as_uint(r2) >> 16);
+    }
+}
+
 int launch_split_pack(const float* w, float* out, int taps, int rows, int cin, int nq, long long base, long long st,
                       long long sq, long long sn, long long sc, hipStream_t s) {
     SplitPack a;
@@ -1028,6 +1080,32 @@ extern "C" int ddpm_pack_conv3x3(const float* w, int cout, int cin, int flip, fl
     const int grid = static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     pack_conv3x3_kernel<<<grid, 256, 0, as_stream(stream)>>>(w, cout, cin, flip, out);
     return ddpm::check_launch("pack_conv3x3_kernel");
+}
+
+extern "C" int ddpm_pack_conv3x3_batch(int n, const float* const* w, const int* cout, const int* cin, const int* flip, float* const* out,
+                                       void* stream) {
+    DDPM_REQUIRE(n >= 0 && (n == 0 || (w && cout && cin && flip && out)));
+    for (int i = 0; i < n; ++i) DDPM_REQUIRE(w[i] && out[i] && cout[i] > 0 && cin[i] > 0);
+    if (!split_math()) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = ddpm_pack_conv3x3(w[i], cout[i], cin[i], flip[i], out[i], stream)) return rc;
+        return DDPM_OK;
+    }
+    for (int i0 = 0; i0 < n; i0 += kPackBatch) {
+        const int cnt = n - i0 < kPackBatch ? n - i0 : kPackBatch;
+        SplitPackBatch b;
+        int64_t most = 0;
+        for (int k = 0; k < kPackBatch; ++k) {
+            const int i = i0 + (k < cnt ? k : 0);      // unused slots repeat the first item (never selected: gridDim.y = cnt)
+            b.item[k] = flip[i] ? make_split_pack(w[i], out[i], 9, cin[i], cout[i], cin[i], 8, -1, 0, 9, 9ll * cin[i])
+                                : make_split_pack(w[i], out[i], 9, cout[i], cin[i], cout[i], 0, 1, 0, 9ll * cin[i], 9);
+            const int64_t total = 9ll * b.item[k].kc16 * b.item[k].nbp * 512;
+            if (k < cnt && total > most) most = total;
+        }
+        const int gx = static_cast<int>((most + 255) / 256 > 1024 ? 1024 : (most + 255) / 256);
+        pack_split_batch_kernel<<<dim3(gx, cnt), 256, 0, as_stream(stream)>>>(b);
+    }
+    return ddpm::check_launch("pack_split_batch_kernel");
 }
 
 extern "C" int ddpm_pack_convT2x2(const float* w, int cin, int cout, float* out, void* stream) {

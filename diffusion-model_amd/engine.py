@@ -186,6 +186,30 @@ class UNetEngine(TrainMixin):
             return out
         return self._cached("pk3f" if flip else "pk3", (key + ".weight",), build)
 
+    def prepack_conv3(self):
+        """Repack every 3x3 weight whose packed copy is stale, all of them in one batched launch. A training step changes
+        every weight, and the forward and the backward would otherwise repack them one by one as they reach them (forty
+        launches of a few microseconds each). The packed buffers are refilled in place (same stream: kernels enqueued
+        earlier still see the old contents)."""
+        items = []
+        for (kind, key), (stamp, val) in self._cache.items():
+            if kind in ("pk3", "pk3f"):
+                w = self.T(key)
+                now = ((w._version, w.data_ptr()),)
+                if now != stamp and w.is_contiguous():
+                    items.append((kind, key, w, val, now))
+        n = len(items)
+        if n < 2:
+            return
+        ptrs = (C.c_void_p * n)(*[it[2].data_ptr() for it in items])
+        outs = (C.c_void_p * n)(*[it[3].data_ptr() for it in items])
+        cout = (C.c_int * n)(*[it[2].shape[0] for it in items])
+        cin = (C.c_int * n)(*[it[2].shape[1] for it in items])
+        flip = (C.c_int * n)(*[int(it[0] == "pk3f") for it in items])
+        call("ddpm_pack_conv3x3_batch", n, ptrs, cout, cin, flip, outs, _stream())
+        for kind, key, _, val, now in items:
+            self._cache[(kind, key)] = (now, val)
+
     def packed_convT(self, key):
         def build(w):
             out = torch.empty(packed_floats(1, 4 * w.shape[1], w.shape[0]), device=w.device, dtype=torch.float32)

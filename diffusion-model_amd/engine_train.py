@@ -143,6 +143,7 @@ class TrainMixin:
             raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
         x = x.contiguous()
         dev = x.device
+        self.prepack_conv3()          # every 3x3 weight the optimizer has changed, both orientations, in one launch
         bc, v1 = self.base, self.v == 1
         emb = torch.empty((B, self.emb // 2 * 2), device=dev, dtype=torch.float32)
         temb = self.time_embed(t, y, emb_out=emb)

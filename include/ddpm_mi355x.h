@@ -239,6 +239,11 @@ int ddpm_convT2x2_fwd(const ddpm_conv_desc* d, const float* src, const float* w_
  * (diagnostic: plain fp32 MFMA kernels) fp32 [tap][row][cin]. */
 int64_t ddpm_packed_weight_floats(int taps, int rows, int cin);
 int ddpm_pack_conv3x3(const float* w, int cout, int cin, int flip, float* out, void* stream);
+
+/* The same for n weight tensors in one or a few launches (host arrays of n entries each): a training step repacks every
+ * convolution weight after the optimizer step (first-iteration/main.py:84), both orientations. */
+int ddpm_pack_conv3x3_batch(int n, const float* const* w, const int* cout, const int* cin, const int* flip, float* const* out,
+                            void* stream);
 int ddpm_pack_convT2x2(const float* w, int cin, int cout, float* out, void* stream);
 int ddpm_pack_conv1x1(const float* w, int rows, int cin, int transpose, float* out, void* stream);
 
