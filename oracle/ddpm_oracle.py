@@ -168,7 +168,7 @@ def unet_forward(sd, variant, x, t, y=None, train=False):
     bufs = {k: v.clone() for k, v in sd.items() if "running_" in k or k.endswith("num_batches_tracked")}
     n = _Net(sd, variant, train, bufs)
     emb_dim = sd["time_fc1.weight"].shape[1]
-    te = time_embedding(t, emb_dim)
+    te = time_embedding(t, emb_dim).to(x.dtype)       # (a float64 state_dict and input give a float64 restatement)
     temb = [F.linear(te, sd[f"time_fc{i}.weight"], sd[f"time_fc{i}.bias"])[:, :, None, None] for i in (1, 2, 3, 4)]
     if y is not None:                                                    # third-iteration/unet.py:135-145
         le = F.embedding(y, sd["label_embedding.weight"])
