@@ -28,7 +28,7 @@ constexpr int kThreads = 512;
 constexpr int kMaxWeightLds = 120 * 1024;
 
 // 8 consecutive fp32 (two 16-byte loads) -> the three bf16 planes of an MFMA operand fragment.
-__device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+__device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, u32x4& hi, u32x4& mid, u32x4& lo) {
     unsigned u[8], m[8], l[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -46,16 +46,18 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, bf16x8& h
         pm[e] = __builtin_amdgcn_perm(m[2 * e + 1], m[2 * e], 0x07060302u);
         pl[e] = __builtin_amdgcn_perm(l[2 * e + 1], l[2 * e], 0x07060302u);
     }
-    hi = __builtin_bit_cast(bf16x8, ph);
-    mid = __builtin_bit_cast(bf16x8, pm);
-    lo = __builtin_bit_cast(bf16x8, pl);
+    hi = ph;
+    mid = pm;
+    lo = pl;
 }
 
 // One wave's share: row groups g_begin + wr, + 4, ... of the workgroup's run, column blocks nb0 .. nb0 + NBW - 1.
-template <int NBW>
+template <int NBW, bool F16>
 __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned char* wsm, int wr, int nb0, int lane);
 
-template <int NB0, int NB1>   // column blocks of the waves of the first / second column half
+// With F16 the operands are fp16 pairs (conv_common.h): planes 0 and 1 of the packed weights, three MFMAs per step and
+// block, the hi*hi products in `acc` and the cross products in `master`, scaled by 2^-11 and added in the epilogue.
+template <int NB0, int NB1, bool F16>   // column blocks of the waves of the first / second column half
 __global__ __launch_bounds__(kThreads, 1) void conv1x1_resident_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];   // [chunk][column block][plane][lane][16 B]
 
@@ -77,11 +79,11 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_resident_kernel(const Gem
     }
     __syncthreads();
     // the two column halves hold different numbers of blocks: each gets its own straight-line code
-    if (wn == 0) wave_body<NB0>(p, wsm, wr, 0, lane);
-    else if (NB1 > 0) wave_body<(NB1 > 0 ? NB1 : 1)>(p, wsm, wr, NB0, lane);
+    if (wn == 0) wave_body<NB0, F16>(p, wsm, wr, 0, lane);
+    else if (NB1 > 0) wave_body<(NB1 > 0 ? NB1 : 1), F16>(p, wsm, wr, NB0, lane);
 }
 
-template <int NBW>
+template <int NBW, bool F16>
 __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned char* wsm, int wr, int nb0, int lane) {
     const int r = lane & 31, h = lane >> 5;
     const int g_begin = __builtin_amdgcn_readfirstlane(blockIdx.x * p.gpb);
@@ -115,15 +117,15 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
     const unsigned chunk_stride = static_cast<unsigned>(p.nbp) * 3072u;
     // planes 1 and 2 have one register set, refilled for the next step as soon as this step's last term with
     // them has issued; plane 0 is used by the first and by the last term of a step, so it alternates between two
-    bf16x8 bw[NBW][3], bw0[2][NBW];
+    u32x4 bw[NBW][3], bw0[2][NBW];
     auto read_b = [&](int kc, int pl) {
 #pragma unroll
         for (int j = 0; j < NBW; ++j)
-            bw[j][pl] = *reinterpret_cast<const bf16x8*>(wbase + kc * chunk_stride + j * 3072u + pl * 1024u);
+            bw[j][pl] = *reinterpret_cast<const u32x4*>(wbase + kc * chunk_stride + j * 3072u + pl * 1024u);
     };
-    auto read_b0 = [&](bf16x8 (&dst)[NBW], int kc) {
+    auto read_b0 = [&](u32x4 (&dst)[NBW], int kc) {
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(wbase + kc * chunk_stride + j * 3072u);
+        for (int j = 0; j < NBW; ++j) dst[j] = *reinterpret_cast<const u32x4*>(wbase + kc * chunk_stride + j * 3072u);
     };
 
     f32x4 ra[4][2];                 // activations of the next four steps, in flight
@@ -131,7 +133,7 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
     for (int i = 0; i < 4; ++i) load_a(ra[i]);
     read_b0(bw0[0], 0);
     read_b(0, 1);
-    read_b(0, 2);
+    if constexpr (!F16) read_b(0, 2);
 
     f32x16 acc[NBW], master[NBW];
     int kc = 0, t = 0;
@@ -145,39 +147,54 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
         zero(master[j]);
     }
 
-    auto step = [&](f32x4 (&raw)[2], bf16x8 (&b0cur)[NBW], bf16x8 (&b0next)[NBW]) {
-        bf16x8 a0, a1, a2;
-        split8(raw[0], raw[1], a0, a1, a2);
+    auto step = [&](f32x4 (&raw)[2], u32x4 (&b0cur)[NBW], u32x4 (&b0next)[NBW]) {
+        u32x4 a0, a1, a2;
+        if constexpr (F16) split8_f16(raw[0], raw[1], a0, a1);
+        else split8(raw[0], raw[1], a0, a1, a2);
         kc = __builtin_amdgcn_readfirstlane(kc);
         t = __builtin_amdgcn_readfirstlane(t);
         if (!(DDPM_C1R_ABLATE & 2)) load_a(raw);              // this register set now carries step s + 4
         const int kn = kc + 1 == kc16 ? 0 : kc + 1;
-        auto term = [&](const bf16x8& a, int pb) {
+        auto term = [&](f32x16 (&c)[NBW], const u32x4& a, int pb) {
 #pragma unroll
             for (int j = 0; j < NBW; ++j) {
-                const bf16x8& b = pb == 0 ? b0cur[j] : bw[j][pb];
-                if (!(DDPM_C1R_ABLATE & 4)) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-                else acc[j][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, a)[0] ^ __builtin_bit_cast(u32x4, b)[1]);
+                const u32x4& b = pb == 0 ? b0cur[j] : bw[j][pb];
+                if (!(DDPM_C1R_ABLATE & 4)) c[j] = mfma16<F16>(a, b, c[j]);
+                else c[j][0] += __builtin_bit_cast(float, a[0] ^ b[1]);
             }
         };
-        // The order of the six products (smallest first) and the fold interval are those of the generic GEMM
+        // The order of the products (smallest first) and the fold interval are those of the generic GEMM
         // kernel, so that both kernels produce the same bits for the same rows (which kernel runs depends on the
         // number of rows, and a result must not depend on how a batch was cut).
-        read_b0(b0next, kn);
-        term(a2, 0);
-        term(a0, 2);
-        read_b(kn, 2);
-        term(a1, 1);
-        term(a1, 0);
-        term(a0, 1);
-        read_b(kn, 1);
-        term(a0, 0);
         const bool last = kc + 1 == kc16;
-        if ((kc & (XFLUSH - 1)) == XFLUSH - 1 || last) {
+        read_b0(b0next, kn);
+        if constexpr (F16) {
+            term(master, a1, 0);
+            term(master, a0, 1);
+            read_b(kn, 1);
+            term(acc, a0, 0);
+            if (last) {
 #pragma unroll
-            for (int j = 0; j < NBW; ++j) {
-                master[j] += acc[j];
-                zero(acc[j]);
+                for (int j = 0; j < NBW; ++j) {
+                    master[j] = acc[j] + master[j] * kLoInv;
+                    zero(acc[j]);
+                }
+            }
+        } else {
+            term(acc, a2, 0);
+            term(acc, a0, 2);
+            read_b(kn, 2);
+            term(acc, a1, 1);
+            term(acc, a1, 0);
+            term(acc, a0, 1);
+            read_b(kn, 1);
+            term(acc, a0, 0);
+            if ((kc & (XFLUSH - 1)) == XFLUSH - 1 || last) {
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) {
+                    master[j] += acc[j];
+                    zero(acc[j]);
+                }
             }
         }
         if (last) {
@@ -246,16 +263,21 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
     if (s + 2 < nsteps) step(ra[2], bw0[0], bw0[1]);
 }
 
-template <int NB0, int NB1>
-int launch_one(const GemmParams& p, int grid, int lds, hipStream_t s) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_resident_kernel<NB0, NB1>),
+template <int NB0, int NB1, bool F16>
+int launch_one_math(const GemmParams& p, int grid, int lds, hipStream_t s) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_resident_kernel<NB0, NB1, F16>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMaxWeightLds);
     if (attr != hipSuccess) {
         set_error("conv1x1_resident_kernel: cannot reserve %d bytes of LDS: %s", kMaxWeightLds, hipGetErrorString(attr));
         return DDPM_E_LAUNCH;
     }
-    conv1x1_resident_kernel<NB0, NB1><<<dim3(grid), dim3(kThreads), lds, s>>>(p);
+    conv1x1_resident_kernel<NB0, NB1, F16><<<dim3(grid), dim3(kThreads), lds, s>>>(p);
     return check_launch("conv1x1_resident_kernel");
+}
+
+template <int NB0, int NB1>
+int launch_one(const GemmParams& p, int grid, int lds, hipStream_t s) {
+    return f16_math() ? launch_one_math<NB0, NB1, true>(p, grid, lds, s) : launch_one_math<NB0, NB1, false>(p, grid, lds, s);
 }
 
 // ---- the same kernel for weight matrices that do not fit LDS (256 and 512 channels) ----------------------------
@@ -267,7 +289,7 @@ int launch_one(const GemmParams& p, int grid, int lds, hipStream_t s) {
 // resident kernel and the generic one: the three agree bit for bit.
 constexpr int kSlabChunks = 4;
 
-template <int NBW>
+template <int NBW, bool F16>
 __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned char* wsm, int wr, int nb_in_tile, int nb_first, int nbt,
                                                int g_begin, int g_end, int lane, const __amdgpu_buffer_rsrc_t rs_w, unsigned tile_off) {
     const int tid = threadIdx.x;
@@ -320,16 +342,16 @@ __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned cha
         }
     };
 
-    bf16x8 bw[NBW][3], bw0[2][NBW];
+    u32x4 bw[NBW][3], bw0[2][NBW];
     const unsigned lane_off = static_cast<unsigned>(nb_in_tile) * 3072u + lane * 16u;
     const unsigned char* wcur = wsm;            // current slab buffer + this wave's blocks
     auto read_b = [&](int c, int pl) {
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) bw[j][pl] = *reinterpret_cast<const bf16x8*>(wcur + c * run_bytes + j * 3072u + pl * 1024u);
+        for (int j = 0; j < NBW; ++j) bw[j][pl] = *reinterpret_cast<const u32x4*>(wcur + c * run_bytes + j * 3072u + pl * 1024u);
     };
-    auto read_b0 = [&](bf16x8 (&dst)[NBW], int c) {
+    auto read_b0 = [&](u32x4 (&dst)[NBW], int c) {
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(wcur + c * run_bytes + j * 3072u);
+        for (int j = 0; j < NBW; ++j) dst[j] = *reinterpret_cast<const u32x4*>(wcur + c * run_bytes + j * 3072u);
     };
 
     f32x4 ra[4][2];
@@ -348,27 +370,35 @@ __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned cha
     }
 
     // step c (0..3) of the current slab
-    auto step = [&](int c, f32x4 (&raw)[2], bf16x8 (&b0cur)[NBW], bf16x8 (&b0next)[NBW]) {
-        bf16x8 a0, a1, a2;
-        split8(raw[0], raw[1], a0, a1, a2);
+    auto step = [&](int c, f32x4 (&raw)[2], u32x4 (&b0cur)[NBW], u32x4 (&b0next)[NBW]) {
+        u32x4 a0, a1, a2;
+        if constexpr (F16) split8_f16(raw[0], raw[1], a0, a1);
+        else split8(raw[0], raw[1], a0, a1, a2);
         load_a(raw);
-        auto term = [&](const bf16x8& a, int pb) {
+        auto term = [&](f32x16 (&cc)[NBW], const u32x4& a, int pb) {
 #pragma unroll
             for (int j = 0; j < NBW; ++j) {
-                const bf16x8& b = pb == 0 ? b0cur[j] : bw[j][pb];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                const u32x4& b = pb == 0 ? b0cur[j] : bw[j][pb];
+                cc[j] = mfma16<F16>(a, b, cc[j]);
             }
         };
         const bool more = c + 1 < kSlabChunks;      // the next step's fragments are in this slab
         if (more) read_b0(b0next, c + 1);
-        term(a2, 0);
-        term(a0, 2);
-        if (more) read_b(c + 1, 2);
-        term(a1, 1);
-        term(a1, 0);
-        term(a0, 1);
-        if (more) read_b(c + 1, 1);
-        term(a0, 0);
+        if constexpr (F16) {
+            term(master, a1, 0);
+            term(master, a0, 1);
+            if (more) read_b(c + 1, 1);
+            term(acc, a0, 0);
+        } else {
+            term(acc, a2, 0);
+            term(acc, a0, 2);
+            if (more) read_b(c + 1, 2);
+            term(acc, a1, 1);
+            term(acc, a1, 0);
+            term(acc, a0, 1);
+            if (more) read_b(c + 1, 1);
+            term(acc, a0, 0);
+        }
     };
 
     load_slab(0);
@@ -386,15 +416,23 @@ __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned cha
             wcur = wsm + buf * slab_bytes + lane_off;
             read_b0(bw0[0], 0);
             read_b(0, 1);
-            read_b(0, 2);
+            if constexpr (!F16) read_b(0, 2);
             step(0, ra[0], bw0[0], bw0[1]);
             step(1, ra[1], bw0[1], bw0[0]);
             step(2, ra[2], bw0[0], bw0[1]);
             step(3, ra[3], bw0[1], bw0[0]);
+            if constexpr (!F16) {
 #pragma unroll
-            for (int j = 0; j < NBW; ++j) {          // a slab is one fold interval
-                master[j] += acc[j];
-                zero(acc[j]);
+                for (int j = 0; j < NBW; ++j) {          // a slab is one fold interval
+                    master[j] += acc[j];
+                    zero(acc[j]);
+                }
+            } else if (sl + 1 == nslab) {
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) {
+                    master[j] = acc[j] + master[j] * kLoInv;
+                    zero(acc[j]);
+                }
             }
             if (sl + 1 == nslab) {
                 // ---- epilogue of row group g: bias / folded BatchNorm, residual, activation ----------------
@@ -449,7 +487,7 @@ __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned cha
     }
 }
 
-template <int NB0, int NB1>
+template <int NB0, int NB1, bool F16>
 __global__ __launch_bounds__(kThreads, 1) void conv1x1_slab_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];   // [2][chunk of the slab][block of the tile][plane][lane][16 B]
     constexpr int NBT = NB0 + NB1;
@@ -470,21 +508,26 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_slab_kernel(const GemmPar
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
     const unsigned tile_off = static_cast<unsigned>(ct * NBT) * 3072u;
     if (g_begin >= g_end) return;       // (whole workgroup: no barrier is skipped by part of it)
-    if (wn == 0) slab_wave_body<NB0>(p, wsm, wr, 0, ct * NBT, NBT, g_begin, g_end, lane, rs_w, tile_off);
-    else slab_wave_body<(NB1 > 0 ? NB1 : 1)>(p, wsm, wr, NB0, ct * NBT + NB0, NBT, g_begin, g_end, lane, rs_w, tile_off);
+    if (wn == 0) slab_wave_body<NB0, F16>(p, wsm, wr, 0, ct * NBT, NBT, g_begin, g_end, lane, rs_w, tile_off);
+    else slab_wave_body<(NB1 > 0 ? NB1 : 1), F16>(p, wsm, wr, NB0, ct * NBT + NB0, NBT, g_begin, g_end, lane, rs_w, tile_off);
 }
 
-template <int NB0, int NB1>
-int launch_slab(const GemmParams& p, int grid, int lds, hipStream_t s) {
+template <int NB0, int NB1, bool F16>
+int launch_slab_math(const GemmParams& p, int grid, int lds, hipStream_t s) {
     constexpr int kMax = 2 * kSlabChunks * 6 * 3072;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_slab_kernel<NB0, NB1>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_slab_kernel<NB0, NB1, F16>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
     if (attr != hipSuccess) {
         set_error("conv1x1_slab_kernel: cannot reserve %d bytes of LDS: %s", kMax, hipGetErrorString(attr));
         return DDPM_E_LAUNCH;
     }
-    conv1x1_slab_kernel<NB0, NB1><<<dim3(grid), dim3(kThreads), lds, s>>>(p);
+    conv1x1_slab_kernel<NB0, NB1, F16><<<dim3(grid), dim3(kThreads), lds, s>>>(p);
     return check_launch("conv1x1_slab_kernel");
+}
+
+template <int NB0, int NB1>
+int launch_slab(const GemmParams& p, int grid, int lds, hipStream_t s) {
+    return f16_math() ? launch_slab_math<NB0, NB1, true>(p, grid, lds, s) : launch_slab_math<NB0, NB1, false>(p, grid, lds, s);
 }
 
 // Returns 1 when the shape is not this kernel's (the caller goes on to the generic one).

@@ -22,6 +22,10 @@
 // rows, one pass per tap, into the other LDS buffer: one barrier per chunk.
 // Accuracy scheme as in conv_gemm.hip: six cross products, MFMA partial sums folded into a master
 // accumulator (round-to-nearest) after every chunk.
+//
+// With F16 the operands are fp16 pairs instead (conv_common.h): two planes per row (80-byte LDS rows), three
+// MFMAs per fragment pair -- the hi*hi products in one accumulator, the two cross products in a second one that is
+// scaled by 2^-11 and added after the last chunk -- and no fold.
 #include <type_traits>
 
 #include "conv_common.h"
@@ -40,13 +44,15 @@ constexpr int kMaxLds = 160 * 1024 - 4096;
 constexpr int WM = 2, WN = 2;              // wave grid
 constexpr int BN = WN * 32;
 
-template <bool DUAL>
+template <bool DUAL, bool F16>
 __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     __shared__ __attribute__((aligned(16))) int rowb[256];   // sample index of every tile row, -1 = no such pixel
+    constexpr int XR = F16 ? XROW_F16 : XROW;   // LDS bytes per tile row
+    constexpr int NPL = F16 ? 2 : 3;            // operand planes
 
     const int W = p.in_w, H = p.in_h, HW = H * W;
-    const int HBUF = p.hrows * XROW;
+    const int HBUF = p.hrows * XR;
     const int ZOFF = (2 * HBUF + 255) & ~255;   // 384 bytes of zeros behind the two buffers, 256-byte aligned
 
     const int nwg = gridDim.x;
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
             down[i] = y < H - 1;
             left[i] = x > 0;
             right[i] = x < W - 1;
-            abase[i] = (row + W + 1) * XROW + h * 16;
+            abase[i] = (row + W + 1) * XR + h * 16;
         }
 
         const int pix0 = __builtin_amdgcn_readfirstlane(max(hp0, 0));   // first pixel the tile can touch: base of the descriptors
@@ -147,7 +153,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
         };
         auto store_pass = [&](const f32x4 v, int k, unsigned char* buf) {
             const int L = srow + kPassRows * k;
-            if (L < p.hrows) split_store(v, buf + L * XROW + lq * 8);
+            if (L < p.hrows) {
+                if constexpr (F16) split_store_f16(v, buf + L * XR + lq * 8);
+                else split_store(v, buf + L * XR + lq * 8);
+            }
         };
 
         // prologue: chunk 0 into buffer 0
@@ -179,22 +188,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
                 }
             // Weight fragments alternate between two register sets by tap parity; after tap 8 the first
             // tap of the next chunk is parked in set 1 and moved to set 0 at the top of the chunk.
-            u32x4 bf[2][3];
-            auto load_b = [&](u32x4 (&dst)[3], int tap, int kc) {
+            u32x4 bf[2][NPL];
+            auto load_b = [&](u32x4 (&dst)[NPL], int tap, int kc) {
                 const unsigned base = static_cast<unsigned>(tap) * tap_stride_w + static_cast<unsigned>(kc) * chunk_stride_w;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wcol, base + pl * 1024u, 0);
+                for (int pl = 0; pl < NPL; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wcol, base + pl * 1024u, 0);
             };
             // Activation fragments: plane 2 of the NEXT tap is requested as soon as this tap's only
             // term with plane 2 has issued, plane 1 after its last term, plane 0 at the top of the step
             // (it is needed last): the reads of a step are covered by its own MFMAs.
-            bf16x8 a0[SLA], a1[SLA], a2[SLA];
+            u32x4 a0[SLA], a1[SLA], a2[F16 ? 1 : SLA];
             // Fragment of tap (dy, dx) for row group i: the row at the tap's offset, or -- for a lane whose
             // neighbour in that direction does not exist -- the zero region at the same offset modulo 256,
             // i.e. on the banks the row itself would have used: the read stays conflict-free.
-            auto read_plane = [&](bf16x8 (&dst)[SLA], int curoff, int tap, int pl) {
+            auto read_plane = [&](u32x4 (&dst)[SLA], int curoff, int tap, int pl) {
                 const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                const int off = curoff + (dy * W + dx) * XROW;
+                const int off = curoff + (dy * W + dx) * XR;
 #pragma unroll
                 for (int i = 0; i < SLA; ++i) {
                     const int nat = abase[i] + off;
@@ -204,13 +213,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
                     if (dx < 0) ok = ok && left[i];
                     if (dx > 0) ok = ok && right[i];
                     const int addr = ((DDPM_HALO_ABLATE & 64) || (dy == 0 && dx == 0)) ? nat : (ok ? nat : (ZOFF | (nat & 255)));
-                    dst[i] = *reinterpret_cast<const bf16x8*>(hsm + addr + pl * 32);
+                    dst[i] = *reinterpret_cast<const u32x4*>(hsm + addr + pl * 32);
                 }
             };
-            auto mma = [&](const bf16x8 (&a)[SLA], const u32x4& b) {
+            auto mma = [&](auto& c, const u32x4 (&a)[SLA], const u32x4& b) {
 #pragma unroll
-                for (int i = 0; i < SLA; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
+                for (int i = 0; i < SLA; ++i) c[i] = mfma16<F16>(a[i], b, c[i]);
             };
             if (SL > 0) load_b(bf[1], 0, 0);
             __syncthreads();
@@ -222,9 +230,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
                 f32x4 areg = {0.f, 0.f, 0.f, 0.f}, areg2 = {0.f, 0.f, 0.f, 0.f};
                 if (SL > 0) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) bf[0][pl] = bf[1][pl];
+                    for (int pl = 0; pl < NPL; ++pl) bf[0][pl] = bf[1][pl];
                     if (!(DDPM_HALO_ABLATE & 4)) {
-                        read_plane(a2, curoff, 0, 2);
+                        if constexpr (!F16) read_plane(a2, curoff, 0, 2);
                         read_plane(a1, curoff, 0, 1);
                     }
                 }
@@ -242,18 +250,25 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
                         if (tap < NPASS) areg = load_pass(tap, kc + 1, areg2);
                     }
                     if (SL > 0) {
-                        const u32x4 (&b)[3] = bf[tap & 1];
-                        mma(a2, b[0]);
-                        if (tap < 8 && !(DDPM_HALO_ABLATE & (4 | 32))) read_plane(a2, curoff, tap + 1, 2);
-                        mma(a1, b[1]);
-                        mma(a1, b[0]);
-                        if (tap < 8 && !(DDPM_HALO_ABLATE & (4 | 32))) read_plane(a1, curoff, tap + 1, 1);
-                        mma(a0, b[2]);
-                        mma(a0, b[1]);
-                        mma(a0, b[0]);
+                        const u32x4 (&b)[NPL] = bf[tap & 1];
+                        if constexpr (F16) {
+                            mma(master, a1, b[0]);   // lo * hi
+                            if (tap < 8 && !(DDPM_HALO_ABLATE & (4 | 32))) read_plane(a1, curoff, tap + 1, 1);
+                            mma(master, a0, b[1]);   // hi * lo
+                            mma(acc, a0, b[0]);      // hi * hi
+                        } else {
+                            mma(acc, a2, b[0]);
+                            if (tap < 8 && !(DDPM_HALO_ABLATE & (4 | 32))) read_plane(a2, curoff, tap + 1, 2);
+                            mma(acc, a1, b[1]);
+                            mma(acc, a1, b[0]);
+                            if (tap < 8 && !(DDPM_HALO_ABLATE & (4 | 32))) read_plane(a1, curoff, tap + 1, 1);
+                            mma(acc, a0, b[2]);
+                            mma(acc, a0, b[1]);
+                            mma(acc, a0, b[0]);
+                        }
                     }
                 }
-                if (SL > 0 && (!(DDPM_HALO_ABLATE & 8) || !has_next)) {
+                if (!F16 && SL > 0 && (!(DDPM_HALO_ABLATE & 8) || !has_next)) {
 #pragma unroll
                     for (int i = 0; i < SLA; ++i) {
                         master[i] += acc[i];
@@ -262,6 +277,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
                     }
                 }
                 __syncthreads();
+            }
+            if (F16 && SL > 0) {
+#pragma unroll
+                for (int i = 0; i < SLA; ++i) master[i] = acc[i] + master[i] * kLoInv;
             }
         };
         using T0 = std::integral_constant<int, 0>;
@@ -344,15 +363,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
     }
 }
 
-template <bool DUAL>
+template <bool DUAL, bool F16>
 int launch_one(const GemmParams& p, int grid, int lds, hipStream_t s) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<DUAL>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<DUAL, F16>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     if (attr != hipSuccess) {
         set_error("conv3x3_halo_kernel: cannot reserve %d bytes of LDS: %s", kMaxLds, hipGetErrorString(attr));
         return DDPM_E_LAUNCH;
     }
-    conv3x3_halo_kernel<DUAL><<<dim3(grid), dim3(kThreads), lds, s>>>(p);
+    conv3x3_halo_kernel<DUAL, F16><<<dim3(grid), dim3(kThreads), lds, s>>>(p);
     return check_launch("conv3x3_halo_kernel");
 }
 
@@ -366,7 +385,9 @@ int launch_conv3x3_halo(GemmParams& p, hipStream_t s) {
     if (p.n_total <= 32) return 1;
     if (p.m_total != p.batch * p.in_h * p.in_w) return 1;
     // two workgroups per CU: 2 buffers of hrows rows each and the zero region within half of the LDS
-    const int max_rows = min(NPASS * kPassRows, (160 * 1024 / 2 - 1024 - 256 - 384 - 512) / (2 * XROW));
+    const bool f16 = f16_math();
+    const int xr = f16 ? XROW_F16 : XROW;
+    const int max_rows = min(NPASS * kPassRows, (160 * 1024 / 2 - 1024 - 256 - 384 - 512) / (2 * xr));
     int tg = 0;
     for (int g = 8; g >= 2; g -= 2)
         if (tile_rows(g, p.in_w) <= max_rows) {
@@ -376,7 +397,7 @@ int launch_conv3x3_halo(GemmParams& p, hipStream_t s) {
     if (tg == 0) return 1;
     p.tile_groups = tg;
     p.hrows = tile_rows(tg, p.in_w);
-    const int lds = ((2 * p.hrows * XROW + 255) & ~255) + 384;
+    const int lds = ((2 * p.hrows * xr + 255) & ~255) + 384;
     p.groups_total = (p.m_total + 31) / 32;
     p.kc16 = (p.ctot + XK - 1) / XK;
     p.nbp = (p.n_total + 31) / 32;
@@ -390,7 +411,8 @@ int launch_conv3x3_halo(GemmParams& p, hipStream_t s) {
     p.gpb = (p.groups_total + per_tile - 1) / per_tile;
     const int64_t grid = static_cast<int64_t>((p.groups_total + p.gpb - 1) / p.gpb) * p.n_tiles;
     if (grid <= 0 || grid > 0x7fffffffll) return fail_invalid("conv grid size");
-    return p.c2 > 0 ? launch_one<true>(p, static_cast<int>(grid), lds, s) : launch_one<false>(p, static_cast<int>(grid), lds, s);
+    if (f16) return p.c2 > 0 ? launch_one<true, true>(p, static_cast<int>(grid), lds, s) : launch_one<false, true>(p, static_cast<int>(grid), lds, s);
+    return p.c2 > 0 ? launch_one<true, false>(p, static_cast<int>(grid), lds, s) : launch_one<false, false>(p, static_cast<int>(grid), lds, s);
 }
 
 }  // namespace conv

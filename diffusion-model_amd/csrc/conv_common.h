@@ -117,6 +117,56 @@ static __device__ __forceinline__ void split_store(const f32x4 v, unsigned char*
     *reinterpret_cast<u32x2*>(dst + 64) = lo;
 }
 
+// ---- the fp16 pair scheme -------------------------------------------------------------------
+// x = hi + lo * 2^-11 with hi = RN_fp16(x) and lo = RN_fp16((x - hi) * 2^11): 22-23 significant bits, the remainder
+// scaled so that it keeps its precision whatever x's exponent (fp16 has only five exponent bits). A product a*b is
+// ah*bh + (ah*bl + al*bh) * 2^-11: the hi*hi products accumulate in one MFMA accumulator, the two cross products in
+// a second one that is scaled and added at the end; the dropped al*bl term is below 2^-22 of a*b, zero on average.
+// The fp16 MFMA does not lose bits when it accumulates the way the bf16 one does (measured: no drift over 9216
+// like-signed terms), so no master accumulator is needed. Operands must stay below 65504 in magnitude; values
+// below 2^-14 lose relative (not absolute) precision.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float kLoScale = 2048.0f;
+constexpr float kLoInv = 1.0f / 2048.0f;
+constexpr int XROW_F16 = 80;   // LDS bytes per tile row: two planes of 16 fp16 and 16 bytes of padding (conflict-free 16-byte reads)
+
+static __device__ __forceinline__ void split2_pair(const f32x2 v, unsigned& hi, unsigned& lo) {
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 rem = (v - __builtin_convertvector(h, f32x2)) * kLoScale;
+    const f16x2 l = __builtin_convertvector(rem, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// four consecutive channels of one tile row -> the two fp16 planes of that row (8 bytes each, 32 bytes apart)
+static __device__ __forceinline__ void split_store_f16(const f32x4 v, unsigned char* dst) {
+    unsigned h0, l0, h1, l1;
+    split2_pair(f32x2{v[0], v[1]}, h0, l0);
+    split2_pair(f32x2{v[2], v[3]}, h1, l1);
+    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(dst + 32) = u32x2{l0, l1};
+}
+
+// 8 consecutive fp32 (two 16-byte loads) -> the two fp16 planes of an MFMA operand fragment
+static __device__ __forceinline__ void split8_f16(const f32x4 v0, const f32x4 v1, u32x4& hi, u32x4& lo) {
+    unsigned h[4], l[4];
+    split2_pair(f32x2{v0[0], v0[1]}, h[0], l[0]);
+    split2_pair(f32x2{v0[2], v0[3]}, h[1], l[1]);
+    split2_pair(f32x2{v1[0], v1[1]}, h[2], l[2]);
+    split2_pair(f32x2{v1[2], v1[3]}, h[3], l[3]);
+    hi = u32x4{h[0], h[1], h[2], h[3]};
+    lo = u32x4{l[0], l[1], l[2], l[3]};
+}
+
+// One 32x32x16 MFMA on operand fragments held as four dwords, in either arithmetic.
+template <bool F16>
+static __device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 
 // 3x3 convolution with the activation tile (plus halo) resident in LDS across the nine taps
 // (conv3x3_halo.hip). Returns DDPM_OK after launching, or a positive value when the shape is outside

@@ -321,7 +321,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
 // LDS tile rows hold the three planes of one 16-deep slice (3 x 32 B) padded to 112 B, which makes the
 // 16-byte fragment reads (lane = row) conflict-free. Loads run two steps ahead of the MFMAs: the data
 // of step s+2 is requested during step s, split and written to LDS during step s+1.
-template <int BN, int MODE, bool DUAL>
+//
+// With F16 the operands are fp16 pairs (conv_common.h): planes hi | lo in the same 112-byte rows, three MFMAs per
+// fragment pair, the hi*hi products in `acc` and the cross products in `master`, which is scaled by 2^-11 and added
+// after the last step; no fold.
+template <int BN, int MODE, bool DUAL, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p) {
     constexpr int TN = BN / 64;               // 32-column MFMA tiles per wave (2 x 2 waves)
     constexpr int NB = (BN * 6 + 255) / 256;  // 16-byte weight pieces per thread and step
@@ -455,7 +459,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
             unsigned char* sA = smem[buf];
             unsigned char* sB = smem[buf] + BM * XROW;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) split_store(areg[i], sA + (lrow + 64 * i) * XROW + lq * 8);
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (F16) split_store_f16(areg[i], sA + (lrow + 64 * i) * XROW + lq * 8);
+                else split_store(areg[i], sA + (lrow + 64 * i) * XROW + lq * 8);
+            }
 #pragma unroll
             for (int i = 0; i < NB; ++i)
                 if (NB * 256 == BN * 6 || wlds[i] >= 0) *reinterpret_cast<u32x4*>(sB + wlds[i]) = breg[i];
@@ -491,39 +498,59 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
                 if (SLOTS > 0) {
                     const unsigned char* sA = smem[buf] + (wm * 32 + r) * XROW + h * 16;
                     const unsigned char* sB = smem[buf] + BM * XROW + (wn * TN * 32 + r) * XROW + h * 16;
-                    bf16x8 a[SL][3], b[TN][3];
+                    constexpr int NPL = F16 ? 2 : 3;
+                    u32x4 a[SL][NPL], b[TN][NPL];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
+                    for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) b[j][pl] = *reinterpret_cast<const bf16x8*>(sB + j * 32 * XROW + pl * 32);
+                        for (int j = 0; j < TN; ++j) b[j][pl] = *reinterpret_cast<const u32x4*>(sB + j * 32 * XROW + pl * 32);
 #pragma unroll
-                        for (int i = 0; i < SL; ++i) a[i][pl] = *reinterpret_cast<const bf16x8*>(sA + i * 64 * XROW + pl * 32);
+                        for (int i = 0; i < SL; ++i) a[i][pl] = *reinterpret_cast<const u32x4*>(sA + i * 64 * XROW + pl * 32);
                     }
-                    auto term = [&](int pa, int pb) {
+                    if constexpr (F16) {
+                        auto term = [&](auto& c, int pa, int pb) {
 #pragma unroll
-                        for (int i = 0; i < SL; ++i)
+                            for (int i = 0; i < SL; ++i)
 #pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
-                    };
-                    // smallest products first
-                    term(2, 0);
-                    term(0, 2);
-                    term(1, 1);
-                    if (s + 1 < steps) store_stage(buf ^ 1);
-                    if (s + 2 < steps) load_stage();
-                    term(1, 0);
-                    term(0, 1);
-                    term(0, 0);
-                    if ((s & (XFLUSH - 1)) == XFLUSH - 1 || s + 1 == steps) {
+                                for (int j = 0; j < TN; ++j) c[i][j] = mfma16<true>(a[i][pa], b[j][pb], c[i][j]);
+                        };
+                        term(master, 1, 0);
+                        if (s + 1 < steps) store_stage(buf ^ 1);
+                        if (s + 2 < steps) load_stage();
+                        term(master, 0, 1);
+                        term(acc, 0, 0);
+                        if (s + 1 == steps) {
 #pragma unroll
-                        for (int i = 0; i < SL; ++i)
+                            for (int i = 0; i < SL; ++i)
 #pragma unroll
-                            for (int j = 0; j < TN; ++j) {
-                                master[i][j] += acc[i][j];
+                                for (int j = 0; j < TN; ++j) master[i][j] = acc[i][j] + master[i][j] * kLoInv;
+                        }
+                    } else {
+                        auto term = [&](int pa, int pb) {
 #pragma unroll
-                                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-                            }
+                            for (int i = 0; i < SL; ++i)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<false>(a[i][pa], b[j][pb], acc[i][j]);
+                        };
+                        // smallest products first
+                        term(2, 0);
+                        term(0, 2);
+                        term(1, 1);
+                        if (s + 1 < steps) store_stage(buf ^ 1);
+                        if (s + 2 < steps) load_stage();
+                        term(1, 0);
+                        term(0, 1);
+                        term(0, 0);
+                        if ((s & (XFLUSH - 1)) == XFLUSH - 1 || s + 1 == steps) {
+#pragma unroll
+                            for (int i = 0; i < SL; ++i)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) {
+                                    master[i][j] += acc[i][j];
+#pragma unroll
+                                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                                }
+                        }
                     }
                 } else {
                     if (s + 1 < steps) store_stage(buf ^ 1);
@@ -642,6 +669,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
 }
 
 using ddpm::split_math;
+using ddpm::f16_math;
 
 template <int MODE>
 int launch_gemm(GemmParams& p, hipStream_t s) {
@@ -676,12 +704,13 @@ int launch_gemm(GemmParams& p, hipStream_t s) {
     const dim3 g(static_cast<unsigned>(grid)), b(256);
     const bool dual = p.c2 > 0;
     if (x3) {
+        const bool f16 = ddpm::f16_math();
         if (best_bn == 128) {
-            if (dual) conv_gemm_x3_kernel<128, MODE, true><<<g, b, 0, s>>>(p);
-            else conv_gemm_x3_kernel<128, MODE, false><<<g, b, 0, s>>>(p);
+            if (dual) f16 ? conv_gemm_x3_kernel<128, MODE, true, true><<<g, b, 0, s>>>(p) : conv_gemm_x3_kernel<128, MODE, true, false><<<g, b, 0, s>>>(p);
+            else f16 ? conv_gemm_x3_kernel<128, MODE, false, true><<<g, b, 0, s>>>(p) : conv_gemm_x3_kernel<128, MODE, false, false><<<g, b, 0, s>>>(p);
         } else {
-            if (dual) conv_gemm_x3_kernel<64, MODE, true><<<g, b, 0, s>>>(p);
-            else conv_gemm_x3_kernel<64, MODE, false><<<g, b, 0, s>>>(p);
+            if (dual) f16 ? conv_gemm_x3_kernel<64, MODE, true, true><<<g, b, 0, s>>>(p) : conv_gemm_x3_kernel<64, MODE, true, false><<<g, b, 0, s>>>(p);
+            else f16 ? conv_gemm_x3_kernel<64, MODE, false, true><<<g, b, 0, s>>>(p) : conv_gemm_x3_kernel<64, MODE, false, false><<<g, b, 0, s>>>(p);
         }
         return ddpm::check_launch("conv_gemm_x3_kernel");
     }
@@ -792,6 +821,27 @@ __global__ void pack_convT_dgrad_kernel(const float* __restrict__ w, int cin, in
 }
 
 
+// Element i of the fragment-major packed image (i >> 9 = the 3 KiB block, i & 511 = position in a plane): three
+// bf16 planes, or -- fp16 pair scheme -- hi and scaled remainder in planes 0 and 1, plane 2 unused.
+__device__ __forceinline__ void store_split_element(unsigned short* out, int64_t i, float v, int f16) {
+    unsigned short* o = out + (i >> 9) * 1536 + (i & 511);
+    if (f16) {
+        const _Float16 h = static_cast<_Float16>(v);
+        const _Float16 l = static_cast<_Float16>((v - static_cast<float>(h)) * kLoScale);
+        o[0] = __builtin_bit_cast(unsigned short, h);
+        o[512] = __builtin_bit_cast(unsigned short, l);
+        o[1024] = 0;
+        return;
+    }
+    const unsigned u = __float_as_uint(v);
+    const float r1 = v - __uint_as_float(u & 0xffff0000u);
+    const unsigned m = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(m & 0xffff0000u);
+    o[0] = static_cast<unsigned short>(u >> 16);
+    o[512] = static_cast<unsigned short>(m >> 16);
+    o[1024] = static_cast<unsigned short>(__float_as_uint(r2) >> 16);
+}
+
 // Split-bf16 packing: logical weight W(tap, n, c) = w[base + tap*st + (n / nq)*sq + (n % nq)*sn + c*sc]
 // -> out[tap][c / 16][n / 32][plane][lane][8] (bf16; planes hi | mid | lo), lane = 32*h + n % 32 holding
 // channels 16*(c/16) + 8*h + 0..7: one (tap, chunk, row block, plane) is the 1 KiB MFMA operand
@@ -799,7 +849,7 @@ __global__ void pack_convT_dgrad_kernel(const float* __restrict__ w, int cin, in
 struct SplitPack {
     const float* w;
     unsigned short* out;
-    int taps, rows, cin, kc16, nbp, nq;
+    int taps, rows, cin, kc16, nbp, nq, f16;
     long long base, st, sq, sn, sc;
 };
 
@@ -818,14 +868,7 @@ __global__ void pack_split_kernel(const SplitPack a) {
         const int c = kc * 16 + (fl >> 5) * 8 + j;
         float v = 0.f;
         if (c < a.cin && n < a.rows) v = a.w[a.base + tap * a.st + (n / a.nq) * a.sq + (n % a.nq) * a.sn + c * a.sc];
-        const unsigned u = __float_as_uint(v);
-        const float r1 = v - __uint_as_float(u & 0xffff0000u);
-        const unsigned m = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(m & 0xffff0000u);
-        unsigned short* o = a.out + (i >> 9) * 1536 + fl * 8 + j;
-        o[0] = static_cast<unsigned short>(u >> 16);
-        o[512] = static_cast<unsigned short>(m >> 16);
-        o[1024] = static_cast<unsigned short>(__float_as_uint(r2) >> 16);
+        store_split_element(a.out, i, v, a.f16);
     }
 }
 
@@ -835,24 +878,13 @@ __global__ void pack_split_kernel(const SplitPack a) {
 struct QkvPack {
     const float *qw, *kw, *vw, *qb, *kb, *vb;
     float *out_f, *out_t, *bias;
-    int c, dq, dqp, split;
+    int c, dq, dqp, split, f16;
 };
 
 __device__ __forceinline__ float qkv_weight(const QkvPack& a, int n, int ch) {
     if (n < a.dqp) return n < a.dq ? a.qw[n * a.c + ch] : 0.f;
     if (n < 2 * a.dqp) return n - a.dqp < a.dq ? a.kw[(n - a.dqp) * a.c + ch] : 0.f;
     return a.vw[(n - 2 * a.dqp) * a.c + ch];
-}
-
-__device__ __forceinline__ void store_split_element(unsigned short* out, int64_t i, float v) {
-    const unsigned u = __float_as_uint(v);
-    const float r1 = v - __uint_as_float(u & 0xffff0000u);
-    const unsigned m = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(m & 0xffff0000u);
-    unsigned short* o = out + (i >> 9) * 1536 + (i & 511);
-    o[0] = static_cast<unsigned short>(u >> 16);
-    o[512] = static_cast<unsigned short>(m >> 16);
-    o[1024] = static_cast<unsigned short>(__float_as_uint(r2) >> 16);
 }
 
 __global__ void pack_qkv_kernel(const QkvPack a) {
@@ -865,7 +897,7 @@ __global__ void pack_qkv_kernel(const QkvPack a) {
             const int j = static_cast<int>(i & 7), fl = static_cast<int>((i >> 3) & 63);
             const int nb = static_cast<int>((i >> 9) % nbp), kc = static_cast<int>((i >> 9) / nbp);
             const int n = nb * 32 + (fl & 31), ch = kc * 16 + (fl >> 5) * 8 + j;
-            store_split_element(reinterpret_cast<unsigned short*>(a.out_f), i, (n < lq && ch < a.c) ? qkv_weight(a, n, ch) : 0.f);
+            store_split_element(reinterpret_cast<unsigned short*>(a.out_f), i, (n < lq && ch < a.c) ? qkv_weight(a, n, ch) : 0.f, a.f16);
         }
         // transpose: rows = c, depth = lq
         const int nbt = (a.c + 31) / 32, kct = (lq + 15) / 16;
@@ -873,7 +905,7 @@ __global__ void pack_qkv_kernel(const QkvPack a) {
             const int j = static_cast<int>(i & 7), fl = static_cast<int>((i >> 3) & 63);
             const int nb = static_cast<int>((i >> 9) % nbt), kc = static_cast<int>((i >> 9) / nbt);
             const int ch = nb * 32 + (fl & 31), n = kc * 16 + (fl >> 5) * 8 + j;
-            store_split_element(reinterpret_cast<unsigned short*>(a.out_t), i, (n < lq && ch < a.c) ? qkv_weight(a, n, ch) : 0.f);
+            store_split_element(reinterpret_cast<unsigned short*>(a.out_t), i, (n < lq && ch < a.c) ? qkv_weight(a, n, ch) : 0.f, a.f16);
         }
     } else {
         for (int64_t i = t0; i < static_cast<int64_t>(lq) * a.c; i += stride) {
@@ -903,6 +935,7 @@ SplitPack make_split_pack(const float* w, float* out, int taps, int rows, int ci
     a.kc16 = (cin + 15) / 16;
     a.nbp = (rows + 31) / 32;
     a.nq = nq;
+    a.f16 = f16_math() ? 1 : 0;
     a.base = base;
     a.st = st;
     a.sq = sq;
@@ -933,14 +966,7 @@ __global__ void pack_split_batch_kernel(const SplitPackBatch b) {
         const int c = kc * 16 + (fl >> 5) * 8 + j;
         float v = 0.f;
         if (c < a.cin && n < a.rows) v = a.w[a.base + tap * a.st + (n / a.nq) * a.sq + (n % a.nq) * a.sn + c * a.sc];
-        const unsigned u = __float_as_uint(v);
-        const float r1 = v - __uint_as_float(u & 0xffff0000u);
-        const unsigned m = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(m & 0xffff0000u);
-        unsigned short* o = a.out + (i >> 9) * 1536 + fl * 8 + j;
-        o[0] = static_cast<unsigned short>(u >> 16);
-        o[512] = static_cast<unsigned short>(m >> 16);
-        o[1024] = static_cast<unsigned short>(__float_as_uint(r2) >> 16);
+        store_split_element(a.out, i, v, a.f16);
     }
 }
 
@@ -955,6 +981,7 @@ int launch_split_pack(const float* w, float* out, int taps, int rows, int cin, i
     a.kc16 = (cin + 15) / 16;
     a.nbp = (rows + 31) / 32;
     a.nq = nq;
+    a.f16 = f16_math() ? 1 : 0;
     a.base = base;
     a.st = st;
     a.sq = sq;
@@ -1004,6 +1031,7 @@ extern "C" int ddpm_pack_qkv(const float* qw, const float* kw, const float* vw, 
     a.out_f = w_packed; a.out_t = wt_packed; a.bias = bias;
     a.c = c; a.dq = dq; a.dqp = dqp;
     a.split = split_math() ? 1 : 0;
+    a.f16 = f16_math() ? 1 : 0;
     const int64_t total = static_cast<int64_t>(2 * dqp + c + 31) * (c + 31);
     const int grid = static_cast<int>((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     pack_qkv_kernel<<<grid, 256, 0, as_stream(stream)>>>(a);
