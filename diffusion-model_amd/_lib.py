@@ -89,6 +89,10 @@ _SIGNATURES = {
     "ddpm_inception_split_scores": [P, I64, I32, I32, P, P],
     "ddpm_mean_cov": [P, I64, I32, P, P, P, P],
     "ddpm_adam_step": [I32, P, P, P, P, P, F64, F64, F64, F64, F64, I64, P],
+    "ddpm_grad_amax": [P, I64, P, P],
+    "ddpm_grad_scale": [P, I64, P, P, P],
+    "ddpm_scale_tensors": [I32, P, P, P, P],
+    "ddpm_conv_math": [],
 }
 
 _lib = None
@@ -128,6 +132,11 @@ def exported_symbols():
 def packed_floats(taps, rows, cin):
     """Size, in floats, of the packed weight buffer of a (taps x rows x cin) contraction."""
     return int(lib().ddpm_packed_weight_floats(taps, rows, cin))
+
+
+def conv_math():
+    """Arithmetic of the MFMA-fed convolutions in this process: 'fp32', 'bf16x3' or 'f16x2' (DDPM_CONV_MATH)."""
+    return ("fp32", "bf16x3", "f16x2")[int(lib().ddpm_conv_math())]
 
 
 def call(name, *args):

@@ -11,6 +11,7 @@ using ddpm::as_stream;
 namespace {
 
 constexpr int kThreads = 256;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ inline int grid_for(int64_t work_items, int per_block, int cap = 256 * 16) {
     int64_t g = (work_items + per_block - 1) / per_block;
@@ -353,6 +354,107 @@ extern "C" int ddpm_mse_bwd(const float* pred, const float* target, const float*
     mse_bwd_kernel<<<grid_for(n, kThreads * 4), kThreads, 0, as_stream(stream)>>>(pred, target, gout, n, grad);
     return ddpm::check_launch("mse_bwd_kernel");
 }
+
+// ---- power-of-two scaling of the backward pass ------------------------------------------------
+// The backward pass is linear in the gradient it starts from. With the fp16-pair arithmetic its MFMA operands must
+// sit inside fp16's exponent range, and loss gradients (2 * diff / numel) are far below it; the backward therefore
+// runs on the incoming gradient times a power of two that brings its largest magnitude into [1, 2), and every
+// parameter gradient is multiplied by the inverse power at the end. Both multiplications are exact in fp32.
+// state: three device floats: [0] largest |g| (bit pattern compared as an integer), [1] the scale, [2] its inverse.
+namespace {
+
+__global__ __launch_bounds__(256) void grad_amax_kernel(const float* __restrict__ g, int64_t n, unsigned* __restrict__ state) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+    unsigned m = 0u;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+        const unsigned a = __float_as_uint(g[i]) & 0x7fffffffu;
+        if (a <= 0x7f800000u && a > m) m = a;     // NaNs do not take part; an infinity does (and disables the scaling)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = __shfl_xor(m, o);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(state, m);
+}
+
+__device__ __forceinline__ float scale_for(unsigned amax_bits) {
+    const unsigned e = amax_bits >> 23;           // biased exponent of the largest magnitude
+    if (e == 0u || e >= 254u) return 1.0f;        // zero, subnormal or not finite: leave the gradient as it is
+    return __uint_as_float((254u - e) << 23);     // 2^-(e - 127)
+}
+
+__global__ __launch_bounds__(256) void grad_scale_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ state, float* __restrict__ out) {
+    const float sc = scale_for(__float_as_uint(state[0]));
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) out[i] = g[i] * sc;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        state[1] = sc;
+        state[2] = 1.0f / sc;
+    }
+}
+
+constexpr int kScaleTensors = 96;
+struct ScaleBatch {
+    float* p[kScaleTensors];
+    int64_t n[kScaleTensors];
+};
+
+__global__ __launch_bounds__(256) void scale_tensors_kernel(const ScaleBatch b, const float* __restrict__ factor) {
+    const float f = factor[0];
+    float* __restrict__ p = b.p[blockIdx.y];
+    const int64_t n = b.n[blockIdx.y];
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+    const int64_t tid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t n4 = (reinterpret_cast<uintptr_t>(p) & 15) == 0 ? n >> 2 : 0;
+    for (int64_t i = tid; i < n4; i += stride) {
+        f32x4 v = reinterpret_cast<f32x4*>(p)[i];
+        v *= f;
+        reinterpret_cast<f32x4*>(p)[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + tid; i < n; i += stride) p[i] *= f;
+}
+
+}  // namespace
+
+extern "C" int ddpm_grad_amax(const float* g, int64_t n, float* state, void* stream) {
+    DDPM_REQUIRE(g && state && n > 0);
+    if (hipMemsetAsync(state, 0, 3 * sizeof(float), as_stream(stream)) != hipSuccess) {
+        ddpm::set_error("ddpm_grad_amax: cannot clear the state");
+        return DDPM_E_LAUNCH;
+    }
+    grad_amax_kernel<<<grid_for(n, kThreads * 4), 256, 0, as_stream(stream)>>>(g, n, reinterpret_cast<unsigned*>(state));
+    return ddpm::check_launch("grad_amax_kernel");
+}
+
+extern "C" int ddpm_grad_scale(const float* g, int64_t n, float* state, float* out, void* stream) {
+    DDPM_REQUIRE(g && state && out && n > 0);
+    grad_scale_kernel<<<grid_for(n, kThreads * 4), 256, 0, as_stream(stream)>>>(g, n, state, out);
+    return ddpm::check_launch("grad_scale_kernel");
+}
+
+extern "C" int ddpm_scale_tensors(int ntensors, float* const* tensors, const int64_t* numel, const float* factor, void* stream) {
+    DDPM_REQUIRE(ntensors >= 0 && factor);
+    if (ntensors == 0) return DDPM_OK;
+    DDPM_REQUIRE(tensors && numel);
+    for (int t0 = 0; t0 < ntensors; t0 += kScaleTensors) {
+        ScaleBatch b;
+        const int cnt = ntensors - t0 < kScaleTensors ? ntensors - t0 : kScaleTensors;
+        int64_t longest = 0;
+        for (int i = 0; i < cnt; ++i) {
+            DDPM_REQUIRE(numel[t0 + i] >= 0 && (numel[t0 + i] == 0 || tensors[t0 + i]));
+            b.p[i] = tensors[t0 + i];
+            b.n[i] = numel[t0 + i];
+            if (b.n[i] > longest) longest = b.n[i];
+        }
+        if (longest == 0) continue;
+        const int64_t want = (longest + 1023) / 1024;
+        scale_tensors_kernel<<<dim3(static_cast<unsigned>(want < 128 ? want : 128), cnt), 256, 0, as_stream(stream)>>>(b, factor);
+    }
+    return ddpm::check_launch("scale_tensors_kernel");
+}
+
+extern "C" int ddpm_conv_math(void) { return ddpm::conv_math(); }
 
 extern "C" int ddpm_pool_skip_fwd(const float* x, int ldx, const float* temb, float* skip, int lds_, float* pooled, int ldp,
                                   uint8_t* argmax, int batch, int h, int w, int c, void* stream) {

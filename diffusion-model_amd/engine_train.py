@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from ._lib import ConvDesc, EmbedArgs, EmbedBwdArgs, Epilogue, call, lib, packed_floats
+from ._lib import ConvDesc, EmbedArgs, EmbedBwdArgs, Epilogue, call, conv_math, lib, packed_floats
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -37,6 +37,8 @@ class TrainMixin:
     _s2 = None                                                      # second stream of the backward pass (weight gradients)
     _main_stream = None                                             # the stream the backward itself runs on (set when _s2 is used)
     _use_side = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # diagnostic switch: "0" keeps the backward on one stream
+    _gall = ()          # gradient tensors this backward allocated itself (not slices of an averager's buffer)
+    _gstate = None      # three device floats: largest |incoming gradient|, the backward's power-of-two scale, its inverse
 
     # ------------------------------------------------------------------ scratch
     def _workspace(self, dev):
@@ -62,11 +64,15 @@ class TrainMixin:
         shape = tuple(shape) if isinstance(shape, (tuple, list, torch.Size)) else (int(shape),)
         sink = self.grad_sink
         if sink is None:
-            return (torch.zeros if zero else torch.empty)(shape, device=dev, dtype=torch.float32)
+            t = (torch.zeros if zero else torch.empty)(shape, device=dev, dtype=torch.float32)
+            self._gall.append(t)
+            return t
         n = 1
         for s in shape:
             n *= s
         t = sink.alloc(n, dev).view(shape)
+        if not sink.owns(t):
+            self._gall.append(t)
         if zero:
             t.zero_()
         return t
@@ -354,6 +360,24 @@ class TrainMixin:
         grads, dtemb = {}, [None, None, None, None]
         ws = self._workspace(dev)
         dout = dout.contiguous()
+        self._gall = []
+        # fp16-pair arithmetic: the backward runs on the incoming gradient times the power of two that brings its
+        # largest magnitude into [1, 2) (loss gradients are far below fp16's exponent range), and every parameter
+        # gradient is multiplied by the inverse at the end; both are exact in fp32. Ranks of a data-parallel job
+        # agree on the scale first: their gradients (and global-batch BatchNorm sums) are added to each other.
+        scaled = conv_math() == "f16x2"
+        if scaled:
+            if self._gstate is None or self._gstate.device != dev:
+                self._gstate = torch.zeros(3, device=dev, dtype=torch.float32)
+            st = self._gstate
+            call("ddpm_grad_amax", _ptr(dout), dout.numel(), _ptr(st), _stream())
+            if _dist_active():
+                import torch.distributed as dist
+                from . import parallel
+                parallel.all_reduce_(st[0:1], op=dist.ReduceOp.MAX)
+            d2 = torch.empty_like(dout)
+            call("ddpm_grad_scale", _ptr(dout), dout.numel(), _ptr(st), _ptr(d2), _stream())
+            dout = d2
 
         # final 1x1 conv
         hfin = tape["final_in"]
@@ -448,6 +472,15 @@ class TrainMixin:
         self._gflush()
         if self._s2 is not None:
             torch.cuda.current_stream().wait_stream(self._s2)
+        if scaled:
+            own = [t for t in self._gall if t.numel()]
+            if own:
+                n = len(own)
+                call("ddpm_scale_tensors", n, (C.c_void_p * n)(*[t.data_ptr() for t in own]), (C.c_int64 * n)(*[t.numel() for t in own]),
+                     C.c_void_p(st.data_ptr() + 8), _stream())
+            if self.grad_sink is not None:
+                self.grad_sink.post_scale = st[2:3].clone()     # the averager's slices: unscaled when it finishes
+        self._gall = []
         return grads
 
     def _pack_convT_dgrad(self, wt):

@@ -154,8 +154,13 @@ class BucketedGradientAverager:
         self.engine = model._engine
         self.sizes = None          # slice sizes (floats, aligned) in the order of the backward, once recorded
         self.flat = None
+        self.post_scale = None     # one-element device tensor: factor the backward still owes the slices (power-of-two gradient scaling)
         self._recording = []
         self._reset()
+
+    def owns(self, t):
+        """True when `t` is a slice of the flat buffer (False in the recording step, whose gradients are plain tensors)."""
+        return self.flat is not None and t.untyped_storage().data_ptr() == self.flat.untyped_storage().data_ptr()
 
     def attach(self):
         self.engine.grad_sink = self
@@ -222,7 +227,8 @@ class BucketedGradientAverager:
     def finish(self):
         world, _ = _world(self.group)
         if self.flat is None:
-            # recording step: plain tensors, one flat all-reduce; then build the persistent buffer
+            # recording step: plain tensors (already unscaled by the backward), one flat all-reduce; then build the persistent buffer
+            self.post_scale = None
             average_gradients(list(self.model.parameters()), group=self.group)
             if self._recording:
                 self.sizes = list(self._recording)
@@ -239,6 +245,9 @@ class BucketedGradientAverager:
                 w.wait()                                       # the current stream waits for the collective; the host does not
         if world > 1:
             self.flat.div_(world)
+        if self.post_scale is not None:
+            self.flat.mul_(self.post_scale)                    # exact: a power of two
+            self.post_scale = None
         for name, p in self.model.named_parameters():
             g = self._grads.get(name)
             if g is not None:

@@ -129,6 +129,24 @@ int ddpm_mse_fwd(const float* pred, const float* target, int64_t n, double* part
 int ddpm_mse_bwd(const float* pred, const float* target, const float* gout, int64_t n, float* grad,
                  void* stream);
 
+/* Power-of-two scaling of the backward pass (loss.backward(), first-iteration/main.py:82-83: the reference has no
+ * counterpart because its fp32 kernels need none). With the fp16-pair arithmetic the MFMA operands of the
+ * data-gradient convolutions must sit inside fp16's exponent range and loss gradients (2*diff/numel) are far below
+ * it, so the backward runs on s*g with s the power of two that brings max|g| into [1, 2) and multiplies every
+ * parameter gradient by 1/s at the end; both multiplications are exact in fp32.
+ * state: 3 device floats: [0] max|g|, [1] s, [2] 1/s. ddpm_grad_amax writes [0] (a data-parallel job all-reduces it
+ * with MAX so that every rank uses the same s); ddpm_grad_scale writes out = s*g and [1], [2];
+ * ddpm_scale_tensors multiplies ntensors tensors in place by the device scalar factor[0] (host arrays of device
+ * pointers and element counts, consumed before the call returns). */
+int ddpm_grad_amax(const float* g, int64_t n, float* state, void* stream);
+int ddpm_grad_scale(const float* g, int64_t n, float* state, float* out, void* stream);
+int ddpm_scale_tensors(int ntensors, float* const* tensors, const int64_t* numel, const float* factor, void* stream);
+
+/* Arithmetic of the MFMA-fed convolutions in this process (DDPM_CONV_MATH in the environment, read once):
+ * 0 fp32 MFMA, 1 three bf16 planes per operand and six cross products, 2 fp16 pair and three cross products.
+ * The packed-weight format follows it. No counterpart in the reference (torch picks its own kernels). */
+int ddpm_conv_math(void);
+
 /* Adam update of ntensors tensors (host arrays of device pointers and element counts; the arrays are
  * consumed before the call returns): exp_avg = lerp(exp_avg, grad, 1-beta1); exp_avg_sq = beta2*exp_avg_sq
  * + (1-beta2)*grad^2; param -= lr/(1-beta1^step) * exp_avg / (sqrt(exp_avg_sq)/sqrt(1-beta2^step) + eps);

@@ -104,6 +104,27 @@ def test_ten_adam_steps_match_reference_losses(optimizer):
         assert_close(sd[k].cpu(), torch.from_numpy(g[f"final::{k}"]), 2e-3, k)
 
 
+@pytest.mark.parametrize("factor", [2.0 ** -24, 2.0 ** 20])
+def test_gradients_follow_the_loss_scale_exactly(factor):
+    """The backward is linear in the gradient it starts from. Whatever arithmetic the convolutions use (the fp16-pair
+    scheme normalises the incoming gradient by a power of two because of fp16's exponent range), a loss multiplied by a
+    power of two must give every parameter gradient multiplied by it, to fp32 rounding: a loss gradient of 1e-12 per
+    element must not cost the backward its precision."""
+    g = load_golden("tiny_unet_v2.npz")
+    x, t = torch.from_numpy(g["hw28_x"]).cuda(), torch.from_numpy(g["hw28_t"]).cuda()
+    tgt = torch.from_numpy(g["hw28_tgt"]).cuda()
+    grads = []
+    for f in (1.0, factor):
+        m = build(2, 2).train()
+        loss = torch.nn.MSELoss()(m(x, t), tgt) * f
+        loss.backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    for k, ref in grads[0].items():
+        got = grads[1][k] / factor
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= 2e-6 * scale + 1e-9, k
+
+
 def test_grad_needs_train_mode_and_no_input_grad():
     m = build(1, 1).eval()
     x = torch.zeros(1, 1, 16, 16, device="cuda")
