@@ -13,9 +13,14 @@
 // which the caller has zeroed. A second tiny kernel permutes the packed result into torch's
 // parameter layout.
 #include <cstdlib>
-#include "common.h"
+#include "conv_common.h"
 
 using ddpm::as_stream;
+using ddpm::conv::f16x2;
+using ddpm::conv::f16x8;
+using ddpm::conv::f32x2;
+using ddpm::conv::kLoInv;
+using ddpm::conv::kLoScale;
 
 namespace {
 
@@ -249,20 +254,33 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst) 
     *reinterpret_cast<u32x2*>(dst + 2 * XPLANE) = lo;
 }
 
+__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst) {
+    unsigned h0, l0, h1, l1;
+    ddpm::conv::split2_pair(f32x2{v[0], v[1]}, h0, l0);
+    ddpm::conv::split2_pair(f32x2{v[2], v[3]}, h1, l1);
+    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(dst + XPLANE) = u32x2{l0, l1};
+}
+
 // PAIR (3x3 only): a layer with 64 channels on one side would leave half of the 128 x 128 tile empty. Instead the
 // tile's two 64-wide halves on that side take TWO CONSECUTIVE TAPS of the same 64 channels (five work items along the
 // tap axis instead of nine, the odd one half empty). PAIR = 1: 64 input channels, the halves of the B tile are X at
 // the two taps' offsets. PAIR = 2: 64 output channels; the B tile must be common to both halves, so the sum runs over
 // X's pixels q with A = dY at q - offset of the half's tap (the same products, enumerated from the other side).
-template <int MODE, int PAIR = 0>
+//
+// F16: both operands as fp16 pairs instead (hi, and the remainder scaled by 2^11; conv_common.h): two planes, three
+// MFMAs per fragment pair -- hi*hi into `acc`, the two cross products into `master`, which is scaled by 2^-11 and
+// added at the end -- and no fold (the fp16 MFMA accumulates without drift).
+template <int MODE, int PAIR, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams p) {
     static_assert(PAIR == 0 || MODE == WG_CONV3, "two taps per tile exist for the 3x3 convolution only");
     constexpr int BT = 128;
+    constexpr int NPL = F16 ? 2 : 3;      // operand planes
     constexpr int F4R = BT / 4;           // float4 per tile row
     constexpr int LPT = XKP * F4R / 256;  // float4 loads per thread per operand (2)
     constexpr int RSTEP = 256 / F4R;      // rows between a thread's consecutive loads (8)
-    __shared__ __attribute__((aligned(16))) unsigned char sA[2][3 * XPLANE];
-    __shared__ __attribute__((aligned(16))) unsigned char sB[2][3 * XPLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char sA[2][NPL * XPLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char sB[2][NPL * XPLANE];
 
     // Workgroups are handed to the 8 XCDs round-robin and each XCD has its own L2: renumber so that an
     // XCD runs CONSECUTIVE work items, i.e. the taps and channel tiles that read the same pixels share
@@ -392,19 +410,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int off = (row0 + RSTEP * i) * XROWB + c4 * 8;
-            split4_store(areg[set][i], &sA[buf][off]);
-            split4_store(breg[set][i], &sB[buf][off]);
+            if constexpr (F16) {
+                split4_store_f16(areg[set][i], &sA[buf][off]);
+                split4_store_f16(breg[set][i], &sB[buf][off]);
+            } else {
+                split4_store(areg[set][i], &sA[buf][off]);
+                split4_store(breg[set][i], &sB[buf][off]);
+            }
         }
     };
 
     // transposing reads: lane 4q + c of a 16-lane group names pixel row q (of the lane half's 4j-th
     // quartet) and channels 4c .. 4c+3 of the group's 16; the lane then holds ITS channel for those 4 pixels
     const int tlane = (8 * h + ((lane & 15) >> 2)) * XROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    auto frag = [&](const unsigned char* tile, int block, int pl) -> bf16x8 {
+    auto frag = [&](const unsigned char* tile, int block, int pl) -> s16x8 {
         const unsigned char* src = tile + pl * XPLANE + block * 64 + tlane;
         const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src));
         const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src + 4 * XROWB));
-        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+        return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
     // One K-step from LDS buffer `set`: multiply it, split step + 1 (register set set ^ 1) into the other
@@ -414,65 +437,111 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
     auto step = [&](int set, int s) {
         const unsigned char* tA = sA[set];
         const unsigned char* tB = sB[set];
-        bf16x8 a[2][3], b[2][3];
+        s16x8 a[2][NPL], b[2][NPL];
         auto reads = [&](int pa, int pb) {
             a[0][pa] = frag(tA, wm * 2, pa);
             a[1][pa] = frag(tA, wm * 2 + 1, pa);
             b[0][pb] = frag(tB, wn * 2, pb);
             b[1][pb] = frag(tB, wn * 2 + 1, pb);
         };
-        // split state of the four float4 of step + 1 (two of each operand)
-        unsigned u[4][4], m[4][4], l[4][4];
-        float r1[4][4];
         auto src = [&](int v) -> f32x4 { return v < 2 ? areg[set ^ 1][v] : breg[set ^ 1][v - 2]; };
-        auto stage = [&](int st) {
-            const int v = st / 3, ph = st % 3;
-            if (ph == 0) {
-                const f32x4 x = src(v);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    u[v][e] = __float_as_uint(x[e]);
-                    r1[v][e] = x[e] - __uint_as_float(u[v][e] & 0xffff0000u);
-                }
-            } else if (ph == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    m[v][e] = __float_as_uint(r1[v][e]);
-                    l[v][e] = __float_as_uint(r1[v][e] - __uint_as_float(m[v][e] & 0xffff0000u));
-                }
-            } else {
-                u32x2 hi, mid, lo;
-                hi[0] = __builtin_amdgcn_perm(u[v][1], u[v][0], 0x07060302u);
-                hi[1] = __builtin_amdgcn_perm(u[v][3], u[v][2], 0x07060302u);
-                mid[0] = __builtin_amdgcn_perm(m[v][1], m[v][0], 0x07060302u);
-                mid[1] = __builtin_amdgcn_perm(m[v][3], m[v][2], 0x07060302u);
-                lo[0] = __builtin_amdgcn_perm(l[v][1], l[v][0], 0x07060302u);
-                lo[1] = __builtin_amdgcn_perm(l[v][3], l[v][2], 0x07060302u);
-                unsigned char* dst = (v < 2 ? &sA[set ^ 1][0] : &sB[set ^ 1][0]) + (row0 + RSTEP * (v & 1)) * XROWB + c4 * 8;
-                *reinterpret_cast<u32x2*>(dst) = hi;
-                *reinterpret_cast<u32x2*>(dst + XPLANE) = mid;
-                *reinterpret_cast<u32x2*>(dst + 2 * XPLANE) = lo;
-            }
-        };
-        auto mfma = [&](int k) {
-            const int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
-            const int t = k >> 2, i = (k >> 1) & 1, j = k & 1;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa[t]], b[j][pb[t]], acc[i][j], 0, 0, 0);
+        auto dst_of = [&](int v) -> unsigned char* {
+            return (v < 2 ? &sA[set ^ 1][0] : &sB[set ^ 1][0]) + (row0 + RSTEP * (v & 1)) * XROWB + c4 * 8;
         };
 #ifndef DDPM_WG_ABLATE
 #define DDPM_WG_ABLATE 0   // diagnostic builds only: 1 no split stages, 2 no global loads, 4 no barrier, 8 no matrix ops
 #endif
-        reads(2, 0);
-        reads(0, 2);
-        reads(1, 1);
-        if (!(DDPM_WG_ABLATE & 2)) load_global(set);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (F16) {
+            // split state of the four float4 of step + 1 (two of each operand): eight stages, one behind each of the
+            // first eight matrix instructions
+            unsigned hi2[4][2];
+            f32x2 rem[4][2];
+            auto stage = [&](int st) {
+                const int v = st >> 1;
+                if ((st & 1) == 0) {
+                    const f32x4 x = src(v);
 #pragma unroll
-        for (int k = 0; k < 24; ++k) {
-            if (!(DDPM_WG_ABLATE & 8) || p.taps == 77) mfma(k);
-            else acc[(k >> 1) & 1][k & 1][k & 15] += static_cast<float>(a[(k >> 1) & 1][k % 3][0]) + static_cast<float>(b[k & 1][k % 3][1]);
-            if ((k & 1) && (!(DDPM_WG_ABLATE & 1) || p.taps == 77)) stage(k >> 1);
+                    for (int q = 0; q < 2; ++q) {
+                        const f32x2 xv = {x[2 * q], x[2 * q + 1]};
+                        const f16x2 hh = __builtin_convertvector(xv, f16x2);
+                        hi2[v][q] = __builtin_bit_cast(unsigned, hh);
+                        rem[v][q] = (xv - __builtin_convertvector(hh, f32x2)) * kLoScale;
+                    }
+                } else {
+                    unsigned lo2[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) lo2[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(rem[v][q], f16x2));
+                    unsigned char* dst = dst_of(v);
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{hi2[v][0], hi2[v][1]};
+                    *reinterpret_cast<u32x2*>(dst + XPLANE) = u32x2{lo2[0], lo2[1]};
+                }
+            };
+            auto mfma = [&](int k) {
+                const int t = k >> 2, i = (k >> 1) & 1, j = k & 1;
+                const f16x8 av = __builtin_bit_cast(f16x8, a[i][t == 0 ? 1 : 0]), bv = __builtin_bit_cast(f16x8, b[j][t == 1 ? 1 : 0]);
+                if (t < 2) master[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, master[i][j], 0, 0, 0);   // lo*hi, hi*lo
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[i][j], 0, 0, 0);               // hi*hi
+            };
+            reads(1, 0);
+            reads(0, 1);
+            if (!(DDPM_WG_ABLATE & 2)) load_global(set);
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                mfma(k);
+                if (k < 8 && !(DDPM_WG_ABLATE & 1)) stage(k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // split state of the four float4 of step + 1 (two of each operand)
+            unsigned u[4][4], m[4][4], l[4][4];
+            float r1[4][4];
+            auto stage = [&](int st) {
+                const int v = st / 3, ph = st % 3;
+                if (ph == 0) {
+                    const f32x4 x = src(v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        u[v][e] = __float_as_uint(x[e]);
+                        r1[v][e] = x[e] - __uint_as_float(u[v][e] & 0xffff0000u);
+                    }
+                } else if (ph == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        m[v][e] = __float_as_uint(r1[v][e]);
+                        l[v][e] = __float_as_uint(r1[v][e] - __uint_as_float(m[v][e] & 0xffff0000u));
+                    }
+                } else {
+                    u32x2 hi, mid, lo;
+                    hi[0] = __builtin_amdgcn_perm(u[v][1], u[v][0], 0x07060302u);
+                    hi[1] = __builtin_amdgcn_perm(u[v][3], u[v][2], 0x07060302u);
+                    mid[0] = __builtin_amdgcn_perm(m[v][1], m[v][0], 0x07060302u);
+                    mid[1] = __builtin_amdgcn_perm(m[v][3], m[v][2], 0x07060302u);
+                    lo[0] = __builtin_amdgcn_perm(l[v][1], l[v][0], 0x07060302u);
+                    lo[1] = __builtin_amdgcn_perm(l[v][3], l[v][2], 0x07060302u);
+                    unsigned char* dst = dst_of(v);
+                    *reinterpret_cast<u32x2*>(dst) = hi;
+                    *reinterpret_cast<u32x2*>(dst + XPLANE) = mid;
+                    *reinterpret_cast<u32x2*>(dst + 2 * XPLANE) = lo;
+                }
+            };
+            auto mfma = [&](int k) {
+                const int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+                const int t = k >> 2, i = (k >> 1) & 1, j = k & 1;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][pa[t]]), __builtin_bit_cast(bf16x8, b[j][pb[t]]), acc[i][j], 0, 0, 0);
+            };
+            reads(2, 0);
+            reads(0, 2);
+            reads(1, 1);
+            if (!(DDPM_WG_ABLATE & 2)) load_global(set);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                if (!(DDPM_WG_ABLATE & 8) || p.taps == 77) mfma(k);
+                else acc[(k >> 1) & 1][k & 1][k & 15] += static_cast<float>(a[(k >> 1) & 1][k % 3][0]) + static_cast<float>(b[k & 1][k % 3][1]);
+                if ((k & 1) && (!(DDPM_WG_ABLATE & 1) || p.taps == 77)) stage(k >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (!(DDPM_WG_ABLATE & 4)) __syncthreads();
     };
@@ -490,14 +559,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
             step(0, s);
             step(1, s + 1);
         }
+        if constexpr (!F16) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    master[i][j] += acc[i][j];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                }
+        }
+    }
+    if constexpr (F16) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                master[i][j] += acc[i][j];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-            }
+            for (int j = 0; j < 2; ++j) master[i][j] = acc[i][j] + master[i][j] * kLoInv;
     }
 
     if (wave_tap >= p.taps) return;
@@ -576,18 +653,23 @@ int launch_wgrad(WgradParams& p, hipStream_t s) {
     p.work = static_cast<int>(tiles * splits);
     const int64_t grid = (tiles * splits + 7) / 8 * 8;
     if (int rc = clear_accumulator(p.out, static_cast<int64_t>(p.taps) * p.m_total * p.n_total, s)) return rc;
+    const bool f16 = ddpm::f16_math();
     if constexpr (MODE == WG_CONV3) {
         if (pair == 1) {
-            conv_wgrad_x3_kernel<MODE, 1><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
+            if (f16) conv_wgrad_x3_kernel<MODE, 1, true><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
+            else conv_wgrad_x3_kernel<MODE, 1, false><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
             return ddpm::check_launch("conv_wgrad_x3_kernel");
         }
         if (pair == 2) {
-            conv_wgrad_x3_kernel<MODE, 2><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
+            if (f16) conv_wgrad_x3_kernel<MODE, 2, true><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
+            else conv_wgrad_x3_kernel<MODE, 2, false><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
             return ddpm::check_launch("conv_wgrad_x3_kernel");
         }
     }
-    if (big && ddpm::split_math())
-        conv_wgrad_x3_kernel<MODE><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
+    if (big && f16)
+        conv_wgrad_x3_kernel<MODE, 0, true><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
+    else if (big && ddpm::split_math())
+        conv_wgrad_x3_kernel<MODE, 0, false><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
     else if (big)
         conv_wgrad_kernel<128, MODE><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);
     else
