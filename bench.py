@@ -35,18 +35,31 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
         sys.path.insert(0, p)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # gfx950 dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
-BF16_MFMA_PEAK_TFLOPS = 2516.6    # gfx950 dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
-SPLIT_PRODUCTS = 6                # bf16 MFMA products per fp32 product in the split-bf16 kernels
+BF16_MFMA_PEAK_TFLOPS = 2516.6    # gfx950 dense bf16 / fp16 matrix peak (v_mfma_f32_32x32x16_bf16, ..._f16)
 HBM_PEAK_GBPS = 8000.0            # HBM3E peak of one MI355X
-SUSTAINED_BF16_TFLOPS = 1900.0    # measured: pure-MFMA loop, two waves per SIMD (tools/probe/mfma_power.hip)
 T_FULL = 1000
+
+# The two split arithmetics: 16-bit MFMA products per fp32 product, the rate a loop of nothing but independent MFMAs of
+# that type sustains on this chip (two waves per SIMD, changing operands), and how to say it in the JSON line.
+ARITHMETIC = {
+    "split-bf16": dict(products=6, sustained=1900.0, probe="tools/probe/mfma_power.hip", inst="v_mfma_f32_32x32x16_bf16",
+                       text="fp32 operands split exactly into 3 bf16 terms, 6 cross products per fp32 product on v_mfma_f32_32x32x16_bf16 "
+                            "with fp32 accumulation: achieved/peak count algorithmic fp32 FLOP, peak = bf16 dense peak / 6"),
+    "fp16-pair": dict(products=3, sustained=1640.0, probe="tools/probe/f16x2_probe.hip", inst="v_mfma_f32_32x32x16_f16",
+                      text="fp32 operands as fp16 pairs (hi + remainder scaled by 2^11: 22-23 significant bits), 3 cross products per fp32 "
+                           "product on v_mfma_f32_32x32x16_f16 with fp32 accumulation; error against fp64 below that of the fp32 MFMA "
+                           "(tests/test_gpu_accuracy.py): achieved/peak count algorithmic fp32 FLOP, peak = fp16 dense peak / 3"),
+}
+
+
+def arithmetic_of(label):
+    return next((a for a in ARITHMETIC if a in label), None)
 
 
 def kernel_peak(label):
     """Matrix-core ceiling of a kernel family in algorithmic (fp32) TFLOP/s."""
-    if "split-bf16" in label:
-        return BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
-    return FP32_MFMA_PEAK_TFLOPS
+    a = arithmetic_of(label)
+    return BF16_MFMA_PEAK_TFLOPS / ARITHMETIC[a]["products"] if a else FP32_MFMA_PEAK_TFLOPS
 
 
 WORKLOADS = {
@@ -385,7 +398,8 @@ class Job:
         kernels = {k: dict(sampled_launches=v[2], avg_ms=round(v[1] / v[2] * 1e3, 4), tflops=round(v[0] / v[1] / 1e12, 2),
                            peak_tflops=round(kernel_peak(k), 1), frac=round(v[0] / v[1] / 1e12 / kernel_peak(k), 4),
                            share_of_step=round(v[1] / prof_steps / sec_per_step, 3)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
-        cfg = {"workload": wl["name"], "per_gpu_batch": self.B, "global_batch": total_b}
+        from diffusion_model_amd._lib import conv_math
+        cfg = {"workload": wl["name"], "per_gpu_batch": self.B, "global_batch": total_b, "conv_math": conv_math()}
         if self.sampling:
             cfg.update(T=T_FULL, step="one denoising step as DiffusionModel.sample() runs it: noise draw (%s) + UNet eval forward whose final "
                                       "1x1 conv is fused with the reverse-step update; images/s = global_batch / (T * seconds_per_step)"
@@ -404,7 +418,8 @@ class Job:
         # memory-side bytes per launch of the dominant kernel: not measurable live (hardware counters need their own
         # rocprofv3 --pmc passes), so taken from the newest committed summary of tools/pmc_traffic.sh for this workload
         traffic, traffic_src = None, None
-        kernel_symbol = {"conv3x3_halo<split-bf16>": "conv3x3_halo_kernel", "attention_fwd<split-bf16>": "attention_fwd_x3_kernel"}.get(dom[0])
+        kernel_symbol = {"conv3x3_halo": "conv3x3_halo_kernel", "attention_fwd": "attention_fwd_x3_kernel"}.get(dom[0].split("<")[0]) \
+            if arithmetic_of(dom[0]) else None
         kind = "sample" if self.workload == "sample" else "train"
         tfile = next((f for f in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_{kind}.txt") for r in (3, 2, 1)) if os.path.exists(f)), None)
         if kernel_symbol and self.workload in ("train", "sample") and tfile:
@@ -417,7 +432,7 @@ class Job:
                                    "counts 64 bytes per read request of any size) + WRITE_SIZE in separate passes, profiles/" +
                                    os.path.basename(tfile))
                     break
-        split = "split-bf16" in dom[0]
+        arith = ARITHMETIC.get(arithmetic_of(dom[0]))
         return {
             "metric": wl["metric"], "value": round(value, 4), "unit": wl["unit"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3),
@@ -425,12 +440,11 @@ class Job:
             "config": cfg,
             "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(kernel_peak(dom[0]), 1),
                          "unit": "TFLOP/s", "frac": round(achieved / kernel_peak(dom[0]), 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "sustained_peak": (round(SUSTAINED_BF16_TFLOPS / SPLIT_PRODUCTS, 1) if split else None),
-                         "sustained_peak_note": "a loop of nothing but independent v_mfma_f32_32x32x16_bf16 (tools/probe/mfma_power.hip) "
-                                                "sustains 1.9 PFLOP/s on this chip (1.8 GHz under that load, not the 2.4 GHz of the nominal peak)",
-                         "arithmetic": ("fp32 operands split exactly into 3 bf16 terms, 6 cross products per fp32 product on "
-                                        "v_mfma_f32_32x32x16_bf16 with fp32 accumulation: achieved/peak count algorithmic fp32 FLOP, "
-                                        "peak = bf16 dense peak / 6" if split else "v_mfma_f32_32x32x2_f32"),
+                         "sustained_peak": (round(arith["sustained"] / arith["products"], 1) if arith else None),
+                         "sustained_peak_note": (f"a loop of nothing but independent {arith['inst']} ({arith['probe']}) sustains "
+                                                 f"{arith['sustained'] / 1e3:.2f} PFLOP/s on this chip (1.6-1.8 GHz under that load, not the 2.4 GHz "
+                                                 "of the nominal peak)" if arith else None),
+                         "arithmetic": arith["text"] if arith else "v_mfma_f32_32x32x2_f32",
                          "avg_launch_ms": round(dom[1][1] / dom[1][2] * 1e3, 4), "sampled_launches": dom[1][2],
                          "measured": f"HIP events around every {max(1, args.profile_stride)}-th MFMA launch of the timed steps (rotating over the launch sites)"
                                      if not multi else "HIP events in a 2-step pre-pass before the process group is created"},

@@ -49,9 +49,9 @@ constexpr int kMaxGridX = 1 << 20;
 
 // Arithmetic of the MFMA-fed convolutions, chosen once per process by DDPM_CONV_MATH in the environment:
 //   "f16x2"  every fp32 operand as a pair of fp16 numbers (hi, and the remainder scaled by 2^11), three cross products
-//            per fp32 product on v_mfma_f32_32x32x16_f16;
+//            per fp32 product on v_mfma_f32_32x32x16_f16 (the default);
 //   "bf16x3" every fp32 operand as the exact sum of three bf16 numbers, six cross products on
-//            v_mfma_f32_32x32x16_bf16 (the default);
+//            v_mfma_f32_32x32x16_bf16;
 //   "fp32"   the plain fp32 MFMA kernels and the fp32 packed-weight format: a diagnostic switch for A/B measurements.
 // The packed-weight format follows the mode, so it holds for every kernel that reads packed weights.
 enum ConvMath { kMathFp32 = 0, kMathBf16x3 = 1, kMathF16x2 = 2 };
@@ -59,8 +59,8 @@ inline int conv_math() {
     static const int mode = [] {
         const char* e = getenv("DDPM_CONV_MATH");
         if (e && strcmp(e, "fp32") == 0) return static_cast<int>(kMathFp32);
-        if (e && strcmp(e, "f16x2") == 0) return static_cast<int>(kMathF16x2);
-        return static_cast<int>(kMathBf16x3);
+        if (e && strcmp(e, "bf16x3") == 0) return static_cast<int>(kMathBf16x3);
+        return static_cast<int>(kMathF16x2);
     }();
     return mode;
 }

@@ -15,7 +15,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, EmbedArgs, Epilogue, call, packed_floats
+from ._lib import ConvDesc, EmbedArgs, Epilogue, call, conv_math, packed_floats
 from .engine_train import TrainMixin, UNetFunction
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
@@ -90,11 +90,13 @@ class UNetEngine(TrainMixin):
 
     def _gemm_label(self, kind, m, n):
         """Name of the kernel family the library uses for a forward/data-gradient contraction (profiling label)."""
-        if os.environ.get("DDPM_CONV_MATH") == "fp32":
+        math = conv_math()
+        if math == "fp32":
             return f"conv_gemm_fp32<{kind}>"
+        tag = "split-bf16" if math == "bf16x3" else "fp16-pair"
         if kind == "conv3x3" and n > 32:
-            return "conv3x3_halo<split-bf16>"
-        return f"conv_gemm_x3<{kind},split-bf16>"
+            return f"conv3x3_halo<{tag}>"
+        return f"conv_gemm_x3<{kind},{tag}>"
 
     def _launch(self, label, flops, name, *args):
         if self.prof is None:
@@ -390,7 +392,7 @@ class UNetEngine(TrainMixin):
             lse = torch.empty((b, h * w), device=x.buf.device, dtype=torch.float32)
             save.update(qkv=qkv, raw=raw, lse=lse)
         n = h * w
-        split = n >= 128 and c >= 64 and os.environ.get("DDPM_CONV_MATH") != "fp32"     # mirrors the library's choice
+        split = n >= 128 and c >= 64 and conv_math() != "fp32"     # mirrors the library's choice
         self._launch("attention_fwd<split-bf16>" if split else "attention_fwd<fp32>", 2.0 * b * n * n * (dqp + c), "ddpm_attention_fwd", qkv.ptr, x.ptr, x.ld,
                      _ptr(self.T(key + ".gamma")), out.ptr, out.ld, _ptr(raw), _ptr(lse), _ptr(temb), b, n, c, dqp, _stream())
 

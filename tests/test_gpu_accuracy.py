@@ -1,13 +1,14 @@
-"""fp32-grade accuracy of the split-bf16 convolution kernels, at kernel level.
+"""fp32-grade accuracy of the split-arithmetic convolution kernels, at kernel level.
 
-The forward / data-gradient convolutions compute every fp32 product as six bf16 MFMA products and
-fold the MFMA partial sum into a master accumulator every 64 (generic kernel) or 144 (halo kernel)
-elements of the contraction. The worst case for that scheme is a long contraction over like-signed
-data (a post-ReLU activation against positive weights: no cancellation, so a truncating accumulator
-drifts). Here: K = 9*512 = 4608 on such data, error against an fp64 convolution, compared with the
-error of the plain fp32-MFMA kernels (DDPM_CONV_MATH=fp32, read once at library load, hence a child
-process) on the same operands. The split kernels must be within 2x of the fp32 kernels' error and
-must not carry a systematic bias."""
+The forward / data-gradient convolutions compute every fp32 product on the 16-bit matrix pipe: as three cross
+products of fp16 pairs (hi + remainder scaled by 2^11; the default), or as six cross products of three bf16 planes with
+the MFMA partial sum folded into a master accumulator every 64 (generic kernel) or 144 (halo kernel) elements of
+the contraction. The worst case for both is a long contraction over like-signed data (a post-ReLU activation
+against positive weights: no cancellation, so a truncating accumulator drifts, and dropped cross terms add up).
+Here: K = 9*512 = 4608 on such data and on mixed-sign data, error against an fp64 convolution, for all three
+arithmetics (DDPM_CONV_MATH is read once at library load, hence child processes) on the same operands. Either split
+arithmetic must be at least as accurate as the plain fp32-MFMA kernels and must not carry a systematic bias; the
+fp16 pair must also hold for operands a thousand times smaller and larger (fp16 has five exponent bits)."""
 import ctypes as C
 import os
 import subprocess
@@ -27,8 +28,9 @@ CHILD = """
 import sys, numpy as np, torch
 sys.path[:0] = [{root!r}, {tests!r}]
 import test_gpu_accuracy as T
-x, w = torch.from_numpy(np.load({xp!r})), torch.from_numpy(np.load({wp!r}))
-np.save({op!r}, T.run_conv(x, w).numpy())
+cases = np.load({inp!r})
+names = sorted(set(k[2:] for k in cases.files))
+np.savez({out!r}, **{{n: T.run_conv(torch.from_numpy(cases["x_" + n]), torch.from_numpy(cases["w_" + n])).numpy() for n in names}})
 """
 
 
@@ -45,28 +47,55 @@ def run_conv(x, w):
     return from_nhwc(out)
 
 
-@pytest.mark.parametrize("cout,kernel", [(128, "halo kernel, master fold every 144"), (32, "generic kernel, master fold every 64")])
-@pytest.mark.parametrize("like_signed", [True, False])
-def test_split_bf16_conv_error_is_fp32_grade_at_k4608(tmp_path, cout, kernel, like_signed):
-    assert os.environ.get("DDPM_CONV_MATH") != "fp32", "this test compares the default kernels with the fp32 ones"
-    x, w = rnd((2, 512, 16, 16), 1), rnd((cout, 512, 3, 3), 2, 0.02)
-    if like_signed:
-        x, w = x.abs(), w.abs()
-    ref = F.conv2d(x.double(), w.double(), padding=1)
-    got = run_conv(x, w)
-    xp, wp_, op = (str(tmp_path / n) for n in ("x.npy", "w.npy", "o.npy"))
-    np.save(xp, x.numpy())
-    np.save(wp_, w.numpy())
-    code = CHILD.format(root=ROOT, tests=os.path.join(ROOT, "tests"), xp=xp, wp=wp_, op=op)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DDPM_CONV_MATH="fp32"), capture_output=True, text=True, timeout=200)
-    assert r.returncode == 0, r.stderr[-2000:]
-    fp32 = torch.from_numpy(np.load(op))
-    scale = ref.abs().max().item()
-    e_split, e_fp32 = (got.double() - ref), (fp32.double() - ref)
-    m_split, m_fp32 = e_split.abs().max().item() / scale, e_fp32.abs().max().item() / scale
-    b_split = e_split.mean().item() / scale
-    print(f"\n[accuracy] K=4608 cout={cout} ({kernel}) like_signed={like_signed}: max|err|/max|ref| split-bf16 {m_split:.3e}, "
-          f"fp32 MFMA {m_fp32:.3e}; mean err/max split-bf16 {b_split:+.3e}, fp32 MFMA {e_fp32.mean().item() / scale:+.3e}")
-    assert m_fp32 < 2e-5, "the comparator itself is off"
-    assert m_split <= 2.0 * m_fp32, (m_split, m_fp32)
-    assert abs(b_split) <= 1e-6, f"systematic bias {b_split:+.3e} of the tensor's scale"
+def _cases():
+    out = {}
+    for cout, kernel in ((128, "halo"), (32, "generic")):
+        for like_signed in (True, False):
+            for mag in ((1.0, 2.0 ** -10, 2.0 ** 10) if (cout == 128 and not like_signed) else (1.0,)):
+                x, w = rnd((2, 512, 16, 16), 1) * mag, rnd((cout, 512, 3, 3), 2, 0.02)
+                if like_signed:
+                    x, w = x.abs(), w.abs()
+                out[f"k4608_{kernel}_{'pos' if like_signed else 'mixed'}_{mag:g}"] = (x, w)
+    # K = 9 * 16 = 144: no long sum hides the operands' own representation error (22-23 bits for the fp16 pair)
+    out["k144"] = (rnd((4, 16, 16, 16), 3), rnd((64, 16, 3, 3), 4, 0.1))
+    return out
+
+
+@pytest.fixture(scope="module")
+def errors(tmp_path_factory):
+    """{case: {arithmetic: (max |err| / max |ref|, mean err / max |ref|)}}: every case through the three arithmetics, one child process each."""
+    tmp = tmp_path_factory.mktemp("accuracy")
+    cases = _cases()
+    inp = str(tmp / "cases.npz")
+    np.savez(inp, **{f"x_{n}": x.numpy() for n, (x, w) in cases.items()}, **{f"w_{n}": w.numpy() for n, (x, w) in cases.items()})
+    refs = {n: F.conv2d(x.double(), w.double(), padding=1) for n, (x, w) in cases.items()}
+    res = {n: {} for n in cases}
+    for math in ("fp32", "bf16x3", "f16x2"):
+        out = str(tmp / f"out_{math}.npz")
+        code = CHILD.format(root=ROOT, tests=os.path.join(ROOT, "tests"), inp=inp, out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DDPM_CONV_MATH=math), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = np.load(out)
+        for n, ref in refs.items():
+            e = torch.from_numpy(got[n]).double() - ref
+            scale = ref.abs().max().item()
+            res[n][math] = (e.abs().max().item() / scale, e.mean().item() / scale)
+    for n, v in res.items():
+        print(f"\n[accuracy] {n}: max|err|/max|ref| " + ", ".join(f"{m} {a:.3e}" for m, (a, b) in v.items())
+              + "; mean err/max " + ", ".join(f"{m} {b:+.3e}" for m, (a, b) in v.items()))
+    return res
+
+
+def test_split_conv_error_is_fp32_grade_at_k4608(errors):
+    for n, err in errors.items():
+        if not n.startswith("k4608"):
+            continue
+        assert err["fp32"][0] < 2e-5, "the comparator itself is off"
+        for math in ("bf16x3", "f16x2"):
+            assert err[math][0] <= err["fp32"][0], (n, math, err)
+            assert abs(err[math][1]) <= 2e-7, f"{n} {math}: systematic bias {err[math][1]:+.3e} of the tensor's scale"
+
+
+def test_short_contraction_is_fp32_grade(errors):
+    err = errors["k144"]
+    assert err["f16x2"][0] <= 1.5 * err["fp32"][0] and err["bf16x3"][0] <= 1.5 * err["fp32"][0], err
