@@ -15,7 +15,7 @@
 #include "attention_small.h"
 #include <type_traits>
 
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -248,6 +248,31 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst, 
     *reinterpret_cast<u32x2*>(dst + 2 * plane_stride) = lo;
 }
 
+// The same three helpers for the fp16 pair (hi, and the remainder scaled by 2^11; conv_common.h): two planes.
+__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ddpm::conv::split2_pair(ddpm::conv::f32x2{v[2 * e], v[2 * e + 1]}, h[e], l[e]);
+    hi = u32x4{h[0], h[1], h[2], h[3]};
+    lo = u32x4{l[0], l[1], l[2], l[3]};
+}
+
+__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, int plane_stride) {
+    unsigned h0, l0, h1, l1;
+    ddpm::conv::split2_pair(ddpm::conv::f32x2{v[0], v[1]}, h0, l0);
+    ddpm::conv::split2_pair(ddpm::conv::f32x2{v[2], v[3]}, h1, l1);
+    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(dst + plane_stride) = u32x2{l0, l1};
+}
+
+using ddpm::conv::kLoInv;
+using ddpm::conv::mfma16;
+
+// With F16 (the default arithmetic, DDPM_CONV_MATH) the kernels below take every operand as an fp16 pair instead:
+// two planes, three MFMAs per fragment pair, the hi*hi products in one accumulator and the two cross products in a
+// second one that is scaled by 2^-11 and added when the sum is complete (the scores of a tile before their softmax,
+// the output after the last key tile; the online-softmax factor multiplies both output accumulators).
+//
 // QB = 32-query blocks per wave, NCT = 32-channel blocks per workgroup. Per 32 x 32 tile of scores a wave spends
 // about 1050 cycles of VALU on the softmax and the split of the probabilities, 192 * KC cycles of MFMA on the scores
 // and 384 * NCT cycles of MFMA on the value product: with 64 channels (NCT = 2) the two are level, and every further
@@ -257,14 +282,15 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst, 
 #ifndef DDPM_ATTN_ABLATE
 #define DDPM_ATTN_ABLATE 0   // diagnostic builds only (wrong results): bit 0 no softmax arithmetic, bit 1 no value-product MFMAs, bit 2 no staging in the loop, bit 3 no transposed V reads in the loop; pipelined kernel: bit 4 no softmax slices, bit 5 no staging, bit 6 V fragments of the first pair only, bit 7 no barrier in the loop
 #endif
-template <int DQ, int QB, int NCT>
+template <int DQ, int QB, int NCT, bool F16>
 __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnParams p) {
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
+    constexpr int NPL = F16 ? 2 : 3;            // operand planes
     constexpr int CS = 32 * NCT;
     constexpr int KD = DQ < 16 ? 16 : DQ;       // K/Q depth padded to the MFMA's 16
     constexpr int KC = KD / 16;                 // depth chunks
     constexpr int KPL = KD * 2;                 // bytes of one plane in a K row
-    constexpr int KROW = 3 * KPL + 16;          // K row: hi | mid | lo + pad (row reads conflict-free)
+    constexpr int KROW = NPL * KPL + 16;        // K row: the planes + pad (row reads conflict-free)
     constexpr int VROW = CS * 2 + 64;           // V row of one plane + pad (transposed reads conflict-free)
     constexpr int VPLANE = KT * VROW;
     constexpr int KF4 = KT * DQ / 4;            // float4 per K tile
@@ -273,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
     static_assert(VF4 % 256 == 0, "V tile must split evenly over 256 threads");
 
     __shared__ __attribute__((aligned(16))) unsigned char sK[2][KT * KROW];
-    __shared__ __attribute__((aligned(16))) unsigned char sV[2][3 * VPLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[2][NPL * VPLANE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -289,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
     }
 
     // Q fragments (B operand of S^T = K Q^T): lane (query, h) holds depth 16kc + 8h .. + 7, three planes
-    u32x4 qf[QB][KC][3];
+    u32x4 qf[QB][KC][NPL];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int qi = q0 + 32 * qb + r;
@@ -308,17 +334,21 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
                     v[4 + j] = x1[j];
                 }
             }
-            split8(v, qf[qb][kc][0], qf[qb][kc][1], qf[qb][kc][2]);
+            if constexpr (F16) split8_f16(v, qf[qb][kc][0], qf[qb][kc][1]);
+            else split8(v, qf[qb][kc][0], qf[qb][kc][1], qf[qb][kc][NPL - 1]);
         }
     }
 
-    f32x16 o[QB][NCT];
+    f32x16 o[QB][NCT], ox[F16 ? QB : 1][F16 ? NCT : 1];   // ox: the cross products of the fp16 pair
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int t = 0; t < NCT; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) o[qb][t][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                o[qb][t][e] = 0.f;
+                if constexpr (F16) ox[qb][t][e] = 0.f;
+            }
     float m_run[QB], l_run[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -349,13 +379,17 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
         for (int i = 0; i < KPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (DQ / 4), c4 = f % (DQ / 4);
-            if (f < KF4) split4_store(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL);
+            if (f < KF4) {
+                if constexpr (F16) split4_store_f16(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL);
+                else split4_store(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL);
+            }
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CS / 4), c4 = f % (CS / 4);
-            split4_store(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE);
+            if constexpr (F16) split4_store_f16(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE);
+            else split4_store(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE);
         }
     };
 
@@ -377,37 +411,49 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
         if (more && !(DDPM_ATTN_ABLATE & 4)) load_tile(j0 + KT);
         if (wave_active) {
             // ---- scores: lane = query, register = key rowmap(reg, h)
-            f32x16 s[QB];
+            f32x16 s[QB], sx[F16 ? QB : 1];
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) s[qb][e] = 0.f;
+                for (int e = 0; e < 16; ++e) {
+                    s[qb][e] = 0.f;
+                    if constexpr (F16) sx[qb][e] = 0.f;
+                }
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
-                bf16x8 kf[3];
+                u32x4 kf[NPL];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const bf16x8*>(&sK[buf][r * KROW + pl * KPL + kc * 32 + h * 16]);
-                auto term = [&](int pa, int pb) {
+                for (int pl = 0; pl < NPL; ++pl) kf[pl] = *reinterpret_cast<const u32x4*>(&sK[buf][r * KROW + pl * KPL + kc * 32 + h * 16]);
+                auto term = [&](f32x16 (&acc)[QB], int pa, int pb) {
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb)
-                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[pa], __builtin_bit_cast(bf16x8, qf[qb][kc][pb]), s[qb], 0, 0, 0);
+                    for (int qb = 0; qb < QB; ++qb) acc[qb] = mfma16<F16>(kf[pa], qf[qb][kc][pb], acc[qb]);
                 };
-                term(2, 0);
-                term(0, 2);
-                term(1, 1);
-                term(1, 0);
-                term(0, 1);
-                term(0, 0);
+                if constexpr (F16) {
+                    term(sx, 1, 0);
+                    term(sx, 0, 1);
+                    term(s, 0, 0);
+                } else {
+                    term(s, 2, 0);
+                    term(s, 0, 2);
+                    term(s, 1, 1);
+                    term(s, 1, 0);
+                    term(s, 0, 1);
+                    term(s, 0, 0);
+                }
             }
-            // ---- online softmax, probabilities split into three bf16 planes per 16-key chunk
-            u32x4 pp[QB][2][3];
+            if constexpr (F16) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) s[qb] = s[qb] + sx[qb] * kLoInv;
+            }
+            // ---- online softmax, probabilities split into their planes per 16-key chunk
+            u32x4 pp[QB][2][NPL];
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 if (DDPM_ATTN_ABLATE & 1) {
 #pragma unroll
                     for (int ck = 0; ck < 2; ++ck)
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
+                        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) pp[qb][ck][pl][e] = __float_as_uint(s[qb][(8 * ck + 4 * (pl & 1) + e) & 15]);
                     continue;
@@ -436,14 +482,18 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) o[qb][ct][e] *= alpha;
+                        for (int e = 0; e < 16; ++e) {
+                            o[qb][ct][e] *= alpha;
+                            if constexpr (F16) ox[qb][ct][e] *= alpha;
+                        }
                 }
 #pragma unroll
                 for (int ck = 0; ck < 2; ++ck) {
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = s[qb][8 * ck + j];
-                    split8(v, pp[qb][ck][0], pp[qb][ck][1], pp[qb][ck][2]);
+                    if constexpr (F16) split8_f16(v, pp[qb][ck][0], pp[qb][ck][1]);
+                    else split8(v, pp[qb][ck][0], pp[qb][ck][1], pp[qb][ck][NPL - 1]);
                 }
             }
             // ---- O^T += V^T P^T, two channel blocks at a time with their accumulators taken in turn (an MFMA that
@@ -452,30 +502,43 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
             for (int ck = 0; ck < 2; ++ck) {
 #pragma unroll
                 for (int ct0 = 0; ct0 < NCT; ct0 += 2) {
-                    bf16x8 vf[2][3];
+                    u32x4 vf[2][NPL];
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) {
+                        for (int pl = 0; pl < NPL; ++pl) {
                             if ((DDPM_ATTN_ABLATE & 8) && (ck | ct0 | c2)) {
-                                vf[c2][pl] = __builtin_bit_cast(bf16x8, qf[0][0][pl]);
+                                vf[c2][pl] = qf[0][0][pl];
                                 continue;
                             }
                             const unsigned char* src = &sV[buf][pl * VPLANE + (16 * ck) * VROW + (ct0 + c2) * 64 + vlane];
                             const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src));
                             const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src + 8 * VROW));
-                            vf[c2][pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+                            vf[c2][pl] = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
                         }
-                    const int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+                    if constexpr (F16) {
+                        // lo*hi and hi*lo into the cross accumulator, hi*hi into the main one
+                        const int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        if ((DDPM_ATTN_ABLATE & 2) && k < 5) continue;
+                        for (int k = 0; k < 3; ++k)
 #pragma unroll
-                        for (int c2 = 0; c2 < 2; ++c2)
+                            for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-                            for (int qb = 0; qb < QB; ++qb)
-                                o[qb][ct0 + c2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c2][pa[k]], __builtin_bit_cast(bf16x8, pp[qb][ck][pb[k]]),
-                                                                                          o[qb][ct0 + c2], 0, 0, 0);
+                                for (int qb = 0; qb < QB; ++qb) {
+                                    if (k < 2) ox[qb][ct0 + c2] = mfma16<true>(vf[c2][pa[k]], pp[qb][ck][pb[k]], ox[qb][ct0 + c2]);
+                                    else o[qb][ct0 + c2] = mfma16<true>(vf[c2][pa[k]], pp[qb][ck][pb[k]], o[qb][ct0 + c2]);
+                                }
+                    } else {
+                        const int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            if ((DDPM_ATTN_ABLATE & 2) && k < 5) continue;
+#pragma unroll
+                            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                                for (int qb = 0; qb < QB; ++qb)
+                                    o[qb][ct0 + c2] = mfma16<false>(vf[c2][pa[k]], pp[qb][ck][pb[k]], o[qb][ct0 + c2]);
+                        }
                     }
                 }
             }
@@ -485,6 +548,12 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
     }
 
     if (!wave_active) return;
+    if constexpr (F16) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) o[qb][ct] = o[qb][ct] + ox[qb][ct] * kLoInv;
+    }
     const float g = p.gamma[0];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -524,17 +593,19 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
 // probabilities, and the splitting + LDS stores of the tiles being staged. A VALU instruction issues while the MFMA
 // in front of it executes, so the wave keeps both pipes busy by itself. Same operations on the same values in the
 // same order per query as the kernel above: the results are bit-identical.
-template <int DQ, int NCT, int NW>
+template <int DQ, int NCT, int NW, bool F16>
 __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const AttnParams p) {
     const dim3 bid = ddpm::xcd_block();
+    constexpr int NPL = F16 ? 2 : 3;    // operand planes
+    constexpr int NPR = F16 ? 3 : 6;    // MFMAs per fragment pair
     constexpr int NT = 64 * NW;
     constexpr int CS = 32 * NCT;
-    constexpr int KD = DQ < 16 ? 16 : DQ, KC = KD / 16, KPL = KD * 2, KROW = 3 * KPL + 16;
+    constexpr int KD = DQ < 16 ? 16 : DQ, KC = KD / 16, KPL = KD * 2, KROW = NPL * KPL + 16;
     constexpr int VROW = CS * 2 + 64, VPLANE = KT * VROW;
     constexpr int KF4 = KT * DQ / 4, VF4 = KT * CS / 4;
     constexpr int KPT = (KF4 + NT - 1) / NT, VPT = VF4 / NT;
     static_assert(VF4 % NT == 0, "V tile must split evenly over the workgroup");
-    constexpr int KBUF = KT * KROW, VBUF = 3 * VPLANE;
+    constexpr int KBUF = KT * KROW, VBUF = NPL * VPLANE;
     constexpr float kLog2e = 1.4426950408889634f;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
@@ -554,7 +625,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
         for (int i = tid; i < 3 * KBUF / 4; i += NT) reinterpret_cast<unsigned*>(sK)[i] = 0u;
     }
 
-    u32x4 qf[KC][3];
+    u32x4 qf[KC][NPL];
     {
         const int qi = q0 + r;
 #pragma unroll
@@ -572,15 +643,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
                     v[4 + j] = x1[j];
                 }
             }
-            split8(v, qf[kc][0], qf[kc][1], qf[kc][2]);
+            if constexpr (F16) split8_f16(v, qf[kc][0], qf[kc][1]);
+            else split8(v, qf[kc][0], qf[kc][1], qf[kc][NPL - 1]);
         }
     }
 
-    f32x16 o[NCT];
+    f32x16 o[NCT], ox[F16 ? NCT : 1];   // ox: the cross products of the fp16 pair
 #pragma unroll
     for (int t = 0; t < NCT; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+        for (int e = 0; e < 16; ++e) {
+            o[t][e] = 0.f;
+            if constexpr (F16) ox[t][e] = 0.f;
+        }
     float m_run = -INFINITY, l_run = 0.f;
 
     f32x4 kreg[KPT], vreg[VPT];
@@ -606,43 +681,47 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
     auto store_k1 = [&](int i, unsigned char* dst) {
         const int f = tid + NT * i;
         const int row = f / (DQ / 4), c4 = f % (DQ / 4);
-        if (f < KF4) split4_store(kreg[i], dst + row * KROW + c4 * 8, KPL);
+        if (f < KF4) {
+            if constexpr (F16) split4_store_f16(kreg[i], dst + row * KROW + c4 * 8, KPL);
+            else split4_store(kreg[i], dst + row * KROW + c4 * 8, KPL);
+        }
     };
     auto store_v1 = [&](int i, unsigned char* dst) {
         const int f = tid + NT * i;
         const int row = f / (CS / 4), c4 = f % (CS / 4);
-        split4_store(vreg[i], dst + row * VROW + c4 * 8, VPLANE);
+        if constexpr (F16) split4_store_f16(vreg[i], dst + row * VROW + c4 * 8, VPLANE);
+        else split4_store(vreg[i], dst + row * VROW + c4 * 8, VPLANE);
     };
 
     const int vlane = (4 * h + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     const int tiles = (p.n + KT - 1) / KT;
 
+    // The score MFMAs of one depth chunk, in issue order: (K plane, Q plane, into the cross accumulator?)
+    constexpr int spa[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0}, spb[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
     // scores of one tile: lane = query, register = key rowmap(reg, h)
     auto scores = [&](const unsigned char* kb, f32x16& s) {
+        f32x16 sx;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        for (int e = 0; e < 16; ++e) s[e] = sx[e] = 0.f;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
-            bf16x8 kf[3];
+            u32x4 kf[NPL];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const bf16x8*>(kb + r * KROW + pl * KPL + kc * 32 + h * 16);
-            auto term = [&](int pa, int pb) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[pa], __builtin_bit_cast(bf16x8, qf[kc][pb]), s, 0, 0, 0);
-            };
-            term(2, 0);
-            term(0, 2);
-            term(1, 1);
-            term(1, 0);
-            term(0, 1);
-            term(0, 0);
+            for (int pl = 0; pl < NPL; ++pl) kf[pl] = *reinterpret_cast<const u32x4*>(kb + r * KROW + pl * KPL + kc * 32 + h * 16);
+#pragma unroll
+            for (int k = 0; k < NPR; ++k) {
+                if (F16 && k < 2) sx = mfma16<F16>(kf[spa[k]], qf[kc][spb[k]], sx);
+                else s = mfma16<F16>(kf[spa[k]], qf[kc][spb[k]], s);
+            }
         }
+        if constexpr (F16) s = s + sx * kLoInv;
     };
 
     // The softmax of one tile in 29 slices (the arithmetic of the kernel above, cut up): s holds scores on entry and
     // probabilities after slice 19; pn receives their planes; alpha the factor that the accumulators owe.
     constexpr int SM = 29;
     float mt = 0.f, m_new = 0.f, alpha = 1.f, ps = 0.f;
-    auto softmax_slice = [&](auto ic, f32x16& s, u32x4 (&pn)[2][3], int j0) {
+    auto softmax_slice = [&](auto ic, f32x16& s, u32x4 (&pn)[2][NPL], int j0) {
         constexpr int i = decltype(ic)::value;
         if constexpr (i == 0) {
             if (j0 + KT > p.n) {
@@ -675,22 +754,29 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
         } else {
             // elements 2j, 2j + 1 -> one 32-bit word of each plane
             constexpr int j = i - 21, ck = j >> 2, w = j & 3;
-            unsigned a, b, c;
-            split2(s[2 * j], s[2 * j + 1], a, b, c);
-            pn[ck][0][w] = a;
-            pn[ck][1][w] = b;
-            pn[ck][2][w] = c;
+            if constexpr (F16) {
+                unsigned a, b;
+                ddpm::conv::split2_pair(ddpm::conv::f32x2{s[2 * j], s[2 * j + 1]}, a, b);
+                pn[ck][0][w] = a;
+                pn[ck][1][w] = b;
+            } else {
+                unsigned a, b, c;
+                split2(s[2 * j], s[2 * j + 1], a, b, c);
+                pn[ck][0][w] = a;
+                pn[ck][1][w] = b;
+                pn[ck][NPL - 1][w] = c;
+            }
         }
     };
 
-    auto read_vf = [&](bf16x8 (&vf)[3], const unsigned char* vb, int blk) {
+    auto read_vf = [&](u32x4 (&vf)[NPL], const unsigned char* vb, int blk) {
         const int ck = blk / NCT, ct = blk % NCT;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
             const unsigned char* src = vb + pl * VPLANE + (16 * ck) * VROW + ct * 64 + vlane;
             const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src));
             const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src + 8 * VROW));
-            vf[pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+            vf[pl] = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
         }
     };
 
@@ -709,7 +795,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
     }
     __syncthreads();
 
-    u32x4 pp[2][3];
+    u32x4 pp[2][NPL];
     if (wave_active) {
         f32x16 s0;
         scores(sK, s0);
@@ -722,8 +808,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
     // into the registers the previous one wrote waits for it (measured: a chain of dependent v_mfma_f32_32x32x16_bf16
     // runs at half the rate of two interleaved chains).
     constexpr int NB = 2 * NCT;         // pieces
-    constexpr int M = 6 * NB;           // their MFMAs
-    constexpr int NS = 6 * KC;          // MFMAs of one tile of scores
+    constexpr int M = NPR * NB;         // their MFMAs
+    constexpr int NS = NPR * KC;        // MFMAs of one tile of scores
     constexpr int LEAD = NS + 2;        // value-product MFMAs in front of the first softmax slice (the scores must have left the pipe)
     static_assert(NCT % 2 == 0 && LEAD < M, "pairs of channel blocks; the scores fit in front of the softmax");
     auto body = [&](auto next_tag, int t) {
@@ -739,9 +825,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
         }
         constexpr int P = NEXT ? SM + VPT + KPT : 0;     // VALU slices of this iteration
         if (wave_active) {
-            f32x16 sn;
-            u32x4 pn[2][3];
-            bf16x8 vf[2][2][3], kf[KC][3];
+            f32x16 sn, snx;
+            u32x4 pn[2][NPL];
+            u32x4 vf[2][2][NPL], kf[KC][NPL];
             read_vf(vf[0][0], vb, 0);
             read_vf(vf[0][1], vb, 1);
             if (NEXT) {
@@ -749,37 +835,40 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
 #pragma unroll
                 for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) kf[kc][pl] = *reinterpret_cast<const bf16x8*>(kb + r * KROW + pl * KPL + kc * 32 + h * 16);
+                    for (int pl = 0; pl < NPL; ++pl) kf[kc][pl] = *reinterpret_cast<const u32x4*>(kb + r * KROW + pl * KPL + kc * 32 + h * 16);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) sn[e] = 0.f;
+                for (int e = 0; e < 16; ++e) sn[e] = snx[e] = 0.f;
             }
-            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
             ddpm::static_for<M>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                constexpr int pr = i / 12, k = (i % 12) >> 1, c2 = i & 1;
+                constexpr int pr = i / (2 * NPR), k = (i % (2 * NPR)) >> 1, c2 = i & 1;
                 constexpr int blk = 2 * pr + c2, ck = blk / NCT, ct = blk % NCT;
-                if constexpr (i % 12 == 0 && 2 * pr + 2 < NB) {
+                if constexpr (i % (2 * NPR) == 0 && 2 * pr + 2 < NB) {
                     if constexpr (DDPM_ATTN_ABLATE & 64) {
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) vf[(pr + 1) & 1][q / 3][q % 3] = vf[pr & 1][q / 3][q % 3];
+                        for (int q = 0; q < 2 * NPL; ++q) vf[(pr + 1) & 1][q / NPL][q % NPL] = vf[pr & 1][q / NPL][q % NPL];
                     } else {
                         read_vf(vf[(pr + 1) & 1][0], vb, 2 * pr + 2);
                         read_vf(vf[(pr + 1) & 1][1], vb, 2 * pr + 3);
                     }
                 }
-                o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[pr & 1][c2][pa[k]], __builtin_bit_cast(bf16x8, pp[ck][pb[k]]), o[ct], 0, 0, 0);
+                if constexpr (F16 && k < 2) ox[ct] = mfma16<F16>(vf[pr & 1][c2][spa[k]], pp[ck][spb[k]], ox[ct]);
+                else o[ct] = mfma16<F16>(vf[pr & 1][c2][spa[k]], pp[ck][spb[k]], o[ct]);
                 if constexpr (NEXT) {
-                    if constexpr (i < NS)
-                        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i / 6][pa[i % 6]], __builtin_bit_cast(bf16x8, qf[i / 6][pb[i % 6]]), sn, 0, 0, 0);
+                    if constexpr (i < NS) {
+                        if constexpr (F16 && i % NPR < 2) snx = mfma16<F16>(kf[i / NPR][spa[i % NPR]], qf[i / NPR][spb[i % NPR]], snx);
+                        else sn = mfma16<F16>(kf[i / NPR][spa[i % NPR]], qf[i / NPR][spb[i % NPR]], sn);
+                    }
                     constexpr int lo = i < LEAD ? 0 : (i - LEAD) * P / (M - LEAD);
                     constexpr int hi = i < LEAD ? 0 : (i + 1 == M ? P : (i + 1 - LEAD) * P / (M - LEAD));
                     ddpm::static_for<hi - lo>([&](auto dc) {
                         constexpr int sl = lo + decltype(dc)::value;
                         if constexpr (sl < SM) {
+                            if constexpr (F16 && sl == 0) sn = sn + snx * kLoInv;   // the tile's scores are complete
                             if constexpr (!(DDPM_ATTN_ABLATE & 16)) softmax_slice(std::integral_constant<int, sl>{}, sn, pn, j0n);
                             else if constexpr (sl == 0) {
 #pragma unroll
-                                for (int q = 0; q < 24; ++q) pn[q / 12][(q / 4) % 3][q & 3] = __float_as_uint(sn[q & 15]);
+                                for (int q = 0; q < 8 * NPL; ++q) pn[q / (4 * NPL)][(q / 4) % NPL][q & 3] = __float_as_uint(sn[q & 15]);
                             }
                         } else if constexpr (DDPM_ATTN_ABLATE & 32) {
                         } else if constexpr (sl < SM + VPT) store_v1(sl - SM, vnext);
@@ -793,12 +882,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) o[ct][e] *= alpha;
+                        for (int e = 0; e < 16; ++e) {
+                            o[ct][e] *= alpha;
+                            if constexpr (F16) ox[ct][e] *= alpha;
+                        }
                 }
 #pragma unroll
                 for (int ck = 0; ck < 2; ++ck)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) pp[ck][pl] = pn[ck][pl];
+                    for (int pl = 0; pl < NPL; ++pl) pp[ck][pl] = pn[ck][pl];
             }
         } else if (NEXT) {
             // (the registers pass through an empty asm so that this copy of the splitting code is not merged with the
@@ -824,6 +916,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
     body(std::false_type{}, tiles - 1);
 
     if (!wave_active) return;
+    if constexpr (F16) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) o[ct] = o[ct] + ox[ct] * kLoInv;
+    }
     const float g = p.gamma[0];
     const int qi = q0 + r;
     if (qi >= p.n) return;
@@ -851,16 +947,39 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
     }
 }
 
-template <int DQ, int NCT, int NW>
-int launch_x3p(const AttnParams& p, int batch, hipStream_t s) {
-    constexpr int KD = DQ < 16 ? 16 : DQ;
-    constexpr int lds = 3 * KT * (3 * KD * 2 + 16) + 2 * 3 * KT * (32 * NCT * 2 + 64);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_x3p_kernel<DQ, NCT, NW>),
+template <int DQ, int NCT, int NW, bool F16>
+int launch_x3p_math(const AttnParams& p, int batch, hipStream_t s) {
+    constexpr int KD = DQ < 16 ? 16 : DQ, NPL = F16 ? 2 : 3;
+    constexpr int lds = 3 * KT * (NPL * KD * 2 + 16) + 2 * NPL * KT * (32 * NCT * 2 + 64);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_x3p_kernel<DQ, NCT, NW, F16>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return ddpm::fail_invalid("LDS size for the attention forward");
     const dim3 g((p.n + 32 * NW - 1) / (32 * NW), (p.c + 32 * NCT - 1) / (32 * NCT), batch);
-    attention_fwd_x3p_kernel<DQ, NCT, NW><<<g, 64 * NW, lds, s>>>(p);
+    attention_fwd_x3p_kernel<DQ, NCT, NW, F16><<<g, 64 * NW, lds, s>>>(p);
     return ddpm::check_launch("attention_fwd_x3p_kernel");
+}
+
+// Which calls take the fp16 pair (when it is the process's arithmetic):
+//  * inference calls only (no log-sum-exp requested). A training forward hands its log-sum-exp to the backward
+//    kernels, which recompute the probabilities in the three-plane bf16 arithmetic: scores rounded differently on the
+//    two sides would leave the recomputed rows slightly unnormalised, and the ill-conditioned gradients of the
+//    attention block (query/key weights, gamma) are where that shows (measured on the full-size training step: 3.5
+//    instead of 1-2 times the fp32 CPU reference's own distance from float64). Forward and backward stay on one
+//    arithmetic.
+//  * at most 16 query channels: the pair needs a second set of output accumulators, and with 32 query channels (two
+//    depth chunks of Q and K fragments besides) that no longer fits the register file at two waves per SIMD; that
+//    shape (256 channels, maps of 16 x 16 and smaller) is short anyway.
+template <int DQ>
+bool fp16_pair_call(const AttnParams& p) {
+    return DQ <= 16 && ddpm::f16_math() && p.lse == nullptr;
+}
+
+template <int DQ, int NCT, int NW>
+int launch_x3p(const AttnParams& p, int batch, hipStream_t s) {
+    if constexpr (DQ <= 16) {
+        if (fp16_pair_call<DQ>(p)) return launch_x3p_math<DQ, NCT, NW, true>(p, batch, s);
+    }
+    return launch_x3p_math<DQ, NCT, NW, false>(p, batch, s);
 }
 
 // DDPM_ATTN_PIPE=0 (read once) selects the phase-by-phase kernel instead of the software-pipelined one: a diagnostic
@@ -901,12 +1020,25 @@ int launch_dq(const AttnParams& p, int batch, hipStream_t s) {
         if constexpr (DQ <= 32) {
             if (p.c >= 128 && pipelined_attention()) return launch_x3p<DQ, 4, 4>(p, batch, s);
         }
+        const bool f16 = fp16_pair_call<DQ>(p);
         if (p.c >= 128 && wide_attention()) {
             const dim3 g((p.n + 127) / 128, (p.c + 127) / 128, batch);
-            attention_fwd_x3_kernel<DQ, 1, 4><<<g, 256, 0, s>>>(p);
+            if constexpr (DQ <= 16) {
+                if (f16) {
+                    attention_fwd_x3_kernel<DQ, 1, 4, true><<<g, 256, 0, s>>>(p);
+                    return ddpm::check_launch("attention_fwd_x3_kernel");
+                }
+            }
+            attention_fwd_x3_kernel<DQ, 1, 4, false><<<g, 256, 0, s>>>(p);
         } else {
             const dim3 g((p.n + 255) / 256, (p.c + 63) / 64, batch);
-            attention_fwd_x3_kernel<DQ, 2, 2><<<g, 256, 0, s>>>(p);
+            if constexpr (DQ <= 16) {
+                if (f16) {
+                    attention_fwd_x3_kernel<DQ, 2, 2, true><<<g, 256, 0, s>>>(p);
+                    return ddpm::check_launch("attention_fwd_x3_kernel");
+                }
+            }
+            attention_fwd_x3_kernel<DQ, 2, 2, false><<<g, 256, 0, s>>>(p);
         }
         return ddpm::check_launch("attention_fwd_x3_kernel");
       }

@@ -392,8 +392,12 @@ class UNetEngine(TrainMixin):
             lse = torch.empty((b, h * w), device=x.buf.device, dtype=torch.float32)
             save.update(qkv=qkv, raw=raw, lse=lse)
         n = h * w
-        split = n >= 128 and c >= 64 and conv_math() != "fp32"     # mirrors the library's choice
-        self._launch("attention_fwd<split-bf16>" if split else "attention_fwd<fp32>", 2.0 * b * n * n * (dqp + c), "ddpm_attention_fwd", qkv.ptr, x.ptr, x.ld,
+        # mirrors the library's choice of kernel family (profiling label only)
+        math = conv_math()
+        label = "attention_fwd<fp32>"
+        if n >= 128 and c >= 64 and math != "fp32" and dqp <= 64:
+            label = "attention_fwd<fp16-pair>" if (math == "f16x2" and dqp <= 16 and lse is None) else "attention_fwd<split-bf16>"
+        self._launch(label, 2.0 * b * n * n * (dqp + c), "ddpm_attention_fwd", qkv.ptr, x.ptr, x.ld,
                      _ptr(self.T(key + ".gamma")), out.ptr, out.ld, _ptr(raw), _ptr(lse), _ptr(temb), b, n, c, dqp, _stream())
 
     # ------------------------------------------------------------------ whole network, eval mode

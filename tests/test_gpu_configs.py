@@ -157,8 +157,10 @@ def test_full_size_train_step_against_the_oracle():
         err = (p.grad.cpu().double() - ref).abs().max().item()
         own = (g32[k].double() - ref).abs().max().item()
         tol = max(2e-3 * ref.abs().max().item() + 5e-6, 3.0 * own)
-        worst.append((err / tol, k, err, own))
+        worst.append((err / tol, k, err, own, ref.abs().max().item()))
     worst.sort(reverse=True)
+    print("\n[full-size train step] worst (error / tolerance, tensor, error, float32 oracle's own error, gradient max): "
+          + "; ".join(f"{w[0]:.2f} {w[1]} {w[2]:.2e} {w[3]:.2e} {w[4]:.2e}" for w in worst[:4]))
     assert worst[0][0] <= 1.0, worst[:6]
 
 

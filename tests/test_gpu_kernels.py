@@ -329,6 +329,30 @@ def test_attention_fwd(case):
     assert_close(lse.cpu(), lse_want, TOL, f"attention lse {case}")
 
 
+@pytest.mark.parametrize("case", [(1, 1024, 128, 16), (1, 784, 128, 16), (1, 4096, 64, 8), (1, 4096, 128, 16), (2, 128, 128, 16), (3, 129, 128, 16),
+                                  (1, 200, 160, 8), (2, 333, 64, 8), (2, 257, 96, 8), (2, 160, 256, 32)])
+def test_attention_fwd_inference_call(case):
+    """The call an eval-mode forward makes: no log-sum-exp, no raw output. With the fp16-pair arithmetic these calls (query
+    depth up to 16) run the pair kernels, phase-by-phase and software-pipelined; same references and tolerance as above,
+    and the gated output must agree with the training call's (three-plane bf16 kernels) to the same tolerance."""
+    B, N, c, dq = case
+    dqp = (dq + 7) // 8 * 8
+    x = rnd((B, N, c), 11)
+    q, k, v = rnd((B, N, dq), 12), rnd((B, N, dq), 13) * 2.0, rnd((B, N, c), 14)
+    gamma, temb = torch.tensor([0.61]), rnd((B, c), 15)
+    qkv = torch.zeros((B, N, 2 * dqp + c))
+    qkv[..., :dq], qkv[..., dqp:dqp + dq], qkv[..., 2 * dqp:] = q, k, v
+    a = torch.softmax(torch.bmm(q.double(), k.double().transpose(1, 2)), dim=-1)
+    want = gamma.double() * torch.bmm(a, v.double()) + x.double() + temb.double()[:, None, :]
+    keep = [qkv.cuda(), x.cuda(), gamma.cuda(), temb.cuda()]
+    out = torch.full((B, N, c), float("nan"), device="cuda")
+    call("ddpm_attention_fwd", P(keep[0]), P(keep[1]), c, P(keep[2]), P(out), c, None, None, P(keep[3]), B, N, c, dqp, stream())
+    assert_close(out.cpu(), want, TOL, f"attention, inference call {case}")
+    out2, raw, lse = torch.empty_like(out), torch.empty_like(out), torch.empty((B, N), device="cuda")
+    call("ddpm_attention_fwd", P(keep[0]), P(keep[1]), c, P(keep[2]), P(out2), c, P(raw), P(lse), P(keep[3]), B, N, c, dqp, stream())
+    assert_close(out.cpu(), out2.cpu().double(), TOL, f"attention, inference against training call {case}")
+
+
 def test_attention_large_logits_rescale():
     """One key dominates from a late tile on: forces the online-softmax rescale branch."""
     B, N, c, dq = 1, 160, 32, 8
