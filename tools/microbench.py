@@ -86,7 +86,9 @@ def main():
         g = torch.full((1,), 0.5, device=dev)
         out, raw, lse = torch.empty_like(x), torch.empty_like(x), torch.empty(B, N, device=dev)
         t = timeit(lambda: call("ddpm_attention_fwd", P(qkv), P(x), c, P(g), P(out), c, P(raw), P(lse), None, B, N, c, dq, S()), iters)
-        print(f"attn fwd B={B} N={N} C={c}: {t*1e6:.1f} us  {2.0*B*N*N*(dq+c)/t/1e12:.1f} TFLOP/s")
+        print(f"attn fwd B={B} N={N} C={c}: {t*1e6:.1f} us  {2.0*B*N*N*(dq+c)/t/1e12:.1f} TFLOP/s (training call: raw output and log-sum-exp)")
+        t = timeit(lambda: call("ddpm_attention_fwd", P(qkv), P(x), c, P(g), P(out), c, None, None, None, B, N, c, dq, S()), iters)
+        print(f"attn fwd B={B} N={N} C={c}: {t*1e6:.1f} us  {2.0*B*N*N*(dq+c)/t/1e12:.1f} TFLOP/s (inference call)")
         ws, es = torch.empty(4096, dtype=torch.float64, device=dev), torch.empty(B, N, device=dev)
         dqkv, dg = torch.empty_like(qkv), torch.empty(1, device=dev)
         t = timeit(lambda: call("ddpm_attention_bwd", P(qkv), P(dy), c, P(raw), P(lse), P(g), P(ws), P(es), P(dqkv), P(dg), B, N, c, dq,
