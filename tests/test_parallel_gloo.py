@@ -45,13 +45,26 @@ class ToyEngine:
         self.m = model
 
     def backward(self, scale):
-        grads = {}
+        # as the real backward under the fp16-pair arithmetic: the incoming gradient's largest magnitude, agreed on by all
+        # ranks (MAX), gives a power-of-two factor s; the gradients are produced times s (and summed across ranks in that
+        # state), and whoever owns their storage multiplies by 1 / s once at the end
+        amax = torch.tensor([scale * 3e-6])
+        if dist.is_available() and dist.is_initialized():
+            parallel.all_reduce_(amax, op=dist.ReduceOp.MAX)
+        s = 2.0 ** -int(torch.floor(torch.log2(amax)).item())
+        grads, own = {}, []
         for i, (name, p) in enumerate(reversed(list(self.m.named_parameters()))):
             g = self.grad_sink.alloc(p.numel(), p.device).view(p.shape) if self.grad_sink else torch.empty_like(p)
-            g.copy_(torch.full_like(p, scale * (i + 1)))
+            if self.grad_sink is None or not self.grad_sink.owns(g):
+                own.append(g)
+            g.copy_(torch.full_like(p, scale * (i + 1) * s))
             grads[name] = g
             if self.grad_sink:
                 self.grad_sink.flush(self)
+        for g in own:
+            g.mul_(1.0 / s)
+        if self.grad_sink is not None:
+            self.grad_sink.post_scale = torch.tensor([1.0 / s])
         if self.grad_sink is not None and self.grad_sink.takes_over(grads):
             return
         for name, p in self.m.named_parameters():
