@@ -89,6 +89,9 @@ _SIGNATURES = {
     "ddpm_inception_split_scores": [P, I64, I32, I32, P, P],
     "ddpm_mean_cov": [P, I64, I32, P, P, P, P],
     "ddpm_adam_step": [I32, P, P, P, P, P, F64, F64, F64, F64, F64, I64, P],
+    "ddpm_conv3x3_fwd_stats": [C.POINTER(ConvDesc), P, P, P, C.POINTER(Epilogue), P, P, C.POINTER(C.c_int), P],
+    "ddpm_bn_partials": [P, I32, I64, I32, P, C.POINTER(C.c_int), P],
+    "ddpm_bn_stats_from_partials": [P, I32, I64, I32, F32, F32, P, P, P, P, P],
     "ddpm_grad_amax": [P, I64, P, P],
     "ddpm_grad_scale": [P, I64, P, P, P],
     "ddpm_scale_tensors": [I32, P, P, P, P],

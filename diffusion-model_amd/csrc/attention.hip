@@ -971,7 +971,11 @@ int launch_x3p_math(const AttnParams& p, int batch, hipStream_t s) {
 //    shape (256 channels, maps of 16 x 16 and smaller) is short anyway.
 template <int DQ>
 bool fp16_pair_call(const AttnParams& p) {
-    return DQ <= 16 && ddpm::f16_math() && p.lse == nullptr;
+    static const bool train_too = [] {   // DDPM_ATTN_TRAIN_F16=1: diagnostic switch, the pair for training calls as well
+        const char* e = getenv("DDPM_ATTN_TRAIN_F16");
+        return e && strcmp(e, "1") == 0;
+    }();
+    return DQ <= 16 && ddpm::f16_math() && (p.lse == nullptr || train_too);
 }
 
 template <int DQ, int NCT, int NW>

@@ -422,6 +422,28 @@ extern "C" int ddpm_bn_stats(const float* x, int ldx, int64_t rows, int c, float
     return ddpm::check_launch("bn_stats");
 }
 
+// The two halves of ddpm_bn_stats as separate calls, so that a producer that already holds the values in registers
+// (ddpm_conv3x3_fwd_stats: the 3x3 convolution's epilogue) can leave the partial sums itself and only the finishing
+// kernel runs afterwards.
+extern "C" int ddpm_bn_partials(const float* x, int ldx, int64_t rows, int c, double* partial, int* nblocks, void* stream) {
+    DDPM_REQUIRE(x && partial && nblocks && rows > 0 && c > 0 && (c & 3) == 0 && c <= 1024);
+    DDPM_REQUIRE((ldx & 3) == 0 && ldx >= c && ddpm::aligned16(x));
+    const int nb = partial_blocks(rows, c);
+    bn_stats_partial_kernel<<<nb, kThreads, 0, as_stream(stream)>>>(x, ldx, rows, c, partial);
+    *nblocks = nb;
+    return ddpm::check_launch("bn_stats_partial_kernel");
+}
+
+extern "C" int ddpm_bn_stats_from_partials(const double* partial, int nblocks, int64_t rows, int c, float eps, float momentum, float* mean,
+                                           float* invstd, float* running_mean, float* running_var, void* stream) {
+    DDPM_REQUIRE(partial && nblocks > 0 && mean && invstd && rows > 0 && c > 0 && (c & 3) == 0 && c <= 1024);
+    DDPM_REQUIRE(ddpm::aligned16(mean) && ddpm::aligned16(invstd));
+    DDPM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    bn_stats_final_kernel<<<(c + kFin - 1) / kFin, kThreads, 0, as_stream(stream)>>>(partial, nblocks, rows, c, eps, momentum, mean, invstd,
+                                                                                             running_mean, running_var);
+    return ddpm::check_launch("bn_stats_final_kernel");
+}
+
 // ---- allocation-free variant of ddpm_bn_stats -------------------------------------------------
 // The per-block partial sums live in a file-scope device array instead of a caller workspace, for
 // callers that cannot allocate device memory (code under HIP graph capture, serving loops, harnesses

@@ -26,6 +26,13 @@
 // With F16 the operands are fp16 pairs instead (conv_common.h): two planes per row (80-byte LDS rows), three
 // MFMAs per fragment pair -- the hi*hi products in one accumulator, the two cross products in a second one that is
 // scaled by 2^-11 and added after the last chunk -- and no fold.
+//
+// With STATS the epilogue also sums the values it stores and their squares per output channel (train-mode BatchNorm
+// statistics of the convolution's output without another pass over it): the 16 values of a register block in fp32
+// (round-to-nearest, so the errors of the thousands of blocks of a channel average out), those sums in float64 per lane
+// across the workgroup's whole run, then across the two lane halves and the two waves that share a column block, and one
+// (sum, sum of squares) pair per workgroup and channel goes to p.stat_partial in the layout the BatchNorm finishing
+// kernel reads. The order of every addition is fixed: the result is deterministic.
 #include <type_traits>
 
 #include "conv_common.h"
@@ -44,7 +51,7 @@ constexpr int kMaxLds = 160 * 1024 - 4096;
 constexpr int WM = 2, WN = 2;              // wave grid
 constexpr int BN = WN * 32;
 
-template <bool DUAL, bool F16>
+template <bool DUAL, bool F16, bool STATS>
 __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     __shared__ __attribute__((aligned(16))) int rowb[256];   // sample index of every tile row, -1 = no such pixel
@@ -95,6 +102,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
     const int ntile = (rest + p.tile_groups - 1) / p.tile_groups;
     const int tq = rest / ntile, trem = rest - tq * ntile;
 
+    double stat_sum = 0.0, stat_sq = 0.0;   // STATS: this lane's column, its rows of every tile of the run
     int g0 = g_begin;
     for (int t = first ? -1 : 0; t < ntile; ++t) {
         const int kg = t < 0 ? first : tq + (t < trem ? 1 : 0);
@@ -358,20 +366,50 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
                     const unsigned rel = static_cast<unsigned>(i * WM * 32 + 8 * (e >> 2) + (e & 3));
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, vo + rel * ldo4, 0, 0);
                 }
+                if constexpr (STATS) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (i * WM + wm) * 32 + 8 * (e >> 2) + (e & 3) + hq;
+                        const float x = m0 + row < p.m_total ? v[e] : 0.f;   // rows past the last pixel hold the bias alone
+                        s1 += x;
+                        s2 += x * x;
+                    }
+                    stat_sum += static_cast<double>(s1);
+                    stat_sq += static_cast<double>(s2);
+                }
             }
+        }
+    }
+    if constexpr (STATS) {
+        // the two lane halves hold different rows of the same column; so do the two waves with the same wn
+        stat_sum += __shfl_xor(stat_sum, 32);
+        stat_sq += __shfl_xor(stat_sq, 32);
+        __syncthreads();                       // the last tile's fragment reads are done: the tile buffers are free
+        double* red = reinterpret_cast<double*>(hsm);
+        if (wm == 1 && h == 0) {
+            red[(wn * 32 + r) * 2] = stat_sum;
+            red[(wn * 32 + r) * 2 + 1] = stat_sq;
+        }
+        __syncthreads();
+        const int n = n0 + wn * 32 + r;
+        if (wm == 0 && h == 0 && n < p.n_total) {
+            double* dst = p.stat_partial + static_cast<int64_t>(m_block) * 2 * p.n_total + n;
+            dst[0] = stat_sum + red[(wn * 32 + r) * 2];
+            dst[p.n_total] = stat_sq + red[(wn * 32 + r) * 2 + 1];
         }
     }
 }
 
-template <bool DUAL, bool F16>
+template <bool DUAL, bool F16, bool STATS = false>
 int launch_one(const GemmParams& p, int grid, int lds, hipStream_t s) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<DUAL, F16>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<DUAL, F16, STATS>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     if (attr != hipSuccess) {
         set_error("conv3x3_halo_kernel: cannot reserve %d bytes of LDS: %s", kMaxLds, hipGetErrorString(attr));
         return DDPM_E_LAUNCH;
     }
-    conv3x3_halo_kernel<DUAL, F16><<<dim3(grid), dim3(kThreads), lds, s>>>(p);
+    conv3x3_halo_kernel<DUAL, F16, STATS><<<dim3(grid), dim3(kThreads), lds, s>>>(p);
     return check_launch("conv3x3_halo_kernel");
 }
 
@@ -384,6 +422,7 @@ int launch_conv3x3_halo(GemmParams& p, hipStream_t s) {
     // shapes left to the generic kernel: very few columns, or images too wide for the LDS tile
     if (p.n_total <= 32) return 1;
     if (p.m_total != p.batch * p.in_h * p.in_w) return 1;
+    if (p.stat_partial && p.c2 > 0) return 1;   // statistics in the epilogue: single-source layers only
     // two workgroups per CU: 2 buffers of hrows rows each and the zero region within half of the LDS
     const bool f16 = f16_math();
     const int xr = f16 ? XROW_F16 : XROW;
@@ -411,6 +450,8 @@ int launch_conv3x3_halo(GemmParams& p, hipStream_t s) {
     p.gpb = (p.groups_total + per_tile - 1) / per_tile;
     const int64_t grid = static_cast<int64_t>((p.groups_total + p.gpb - 1) / p.gpb) * p.n_tiles;
     if (grid <= 0 || grid > 0x7fffffffll) return fail_invalid("conv grid size");
+    p.stat_blocks = static_cast<int>(grid) / p.n_tiles;
+    if (p.stat_partial) return f16 ? launch_one<false, true, true>(p, static_cast<int>(grid), lds, s) : launch_one<false, false, true>(p, static_cast<int>(grid), lds, s);
     if (f16) return p.c2 > 0 ? launch_one<true, true>(p, static_cast<int>(grid), lds, s) : launch_one<false, true>(p, static_cast<int>(grid), lds, s);
     return p.c2 > 0 ? launch_one<true, false>(p, static_cast<int>(grid), lds, s) : launch_one<false, false>(p, static_cast<int>(grid), lds, s);
 }

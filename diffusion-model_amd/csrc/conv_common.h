@@ -45,6 +45,8 @@ struct GemmParams {
     int kc16;                            // 16-channel chunks per tap (split-bf16 path)
     int nbp;                             // 32-row blocks of the packed weights (split-bf16 path)
     int tile_groups, hrows;              // halo kernel: row groups per tile, LDS rows per buffer
+    double* stat_partial;                // halo kernel, optional: per-channel partial sums of the values written, [block][sum | sum of squares][cout]
+    int stat_blocks;                     // set by the launcher: number of blocks in stat_partial
 };
 
 static __device__ __forceinline__ float apply_act(float v, int act) {

@@ -771,6 +771,8 @@ void fill_common(GemmParams& p, const ddpm_conv_desc* d, const float* src1, cons
     p.out_w = d->in_w;
     p.off_y = 0;
     p.off_x = 0;
+    p.stat_partial = nullptr;
+    p.stat_blocks = 0;
     p.kc = (p.ctot + BK - 1) / BK;
     p.m_total = d->batch * d->in_h * d->in_w;
     p.src1_pixels = static_cast<long long>(d->batch) * d->in_h * d->in_w;
@@ -1049,6 +1051,28 @@ extern "C" int ddpm_conv3x3_fwd(const ddpm_conv_desc* d, const float* src1, cons
         if (rc <= 0) return rc;   // launched, or failed; positive = shape for the generic kernel
     }
     return launch_gemm<MODE_CONV3>(p, as_stream(stream));
+}
+
+extern "C" int ddpm_conv3x3_fwd_stats(const ddpm_conv_desc* d, const float* src1, const float* src2, const float* w_packed,
+                                      const ddpm_epilogue* ep, float* out, double* partial, int* nblocks, void* stream) {
+    if (int rc = validate_common(d, src1, src2, w_packed, ep, out)) return rc;
+    DDPM_REQUIRE(partial && nblocks && (d->cout & 3) == 0 && d->cout <= 1024);
+    GemmParams p;
+    fill_common(p, d, src1, src2, w_packed, ep, out);
+    p.taps = 9;
+    if (split_math()) {
+        p.stat_partial = partial;
+        const int rc = launch_conv3x3_halo(p, as_stream(stream));
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            *nblocks = p.stat_blocks;
+            return DDPM_OK;
+        }
+        p.stat_partial = nullptr;
+    }
+    // shapes of the generic kernel: the convolution, then the statistics' own pass over its output
+    if (int rc = launch_gemm<MODE_CONV3>(p, as_stream(stream))) return rc;
+    return ddpm_bn_partials(out, d->ldo, static_cast<int64_t>(d->batch) * d->in_h * d->in_w, d->cout, partial, nblocks, stream);
 }
 
 extern "C" int ddpm_conv1x1_fwd(const ddpm_conv_desc* d, const float* src1, const float* src2, const float* w_packed,

@@ -260,6 +260,19 @@ class UNetEngine(TrainMixin):
         self._launch(self._gemm_label("conv3x3", m, cout), 2.0 * m * cout * 9 * src.c, "ddpm_conv3x3_fwd", C.byref(d), src.ptr,
                      None, _ptr(wkey_packed), C.byref(ep), out.ptr, _stream())
 
+    def conv3x3_stats(self, src, wkey_packed, cout, out, bias, partial):
+        """conv3x3 (+bias) into `out` that also leaves the partial sums of train-mode BatchNorm statistics over `out` in
+        `partial` (the engine's float64 reduction workspace); returns the number of partial blocks."""
+        b, h, w = src.bhw
+        d = ConvDesc(batch=b, in_h=h, in_w=w, c1=src.c, ld1=src.ld, c2=0, ld2=0, cout=cout, ldo=out.ld, act=ACT_NONE, ldr=0, out_h=h, out_w=w,
+                     off_y=0, off_x=0)
+        ep = Epilogue(None, _ptr(bias), None, None)
+        m = b * h * w
+        nblk = C.c_int(0)
+        self._launch(self._gemm_label("conv3x3", m, cout), 2.0 * m * cout * 9 * src.c, "ddpm_conv3x3_fwd_stats", C.byref(d), src.ptr,
+                     None, _ptr(wkey_packed), C.byref(ep), out.ptr, _ptr(partial), C.byref(nblk), _stream())
+        return nblk.value
+
     def conv1x1(self, src, w, bias, cout, out):
         b, h, wd = src.bhw
         d = ConvDesc(batch=b, in_h=h, in_w=wd, c1=src.c, ld1=src.ld, c2=0, ld2=0, cout=cout, ldo=out.ld, act=ACT_NONE,

@@ -37,6 +37,7 @@ class TrainMixin:
     _s2 = None                                                      # second stream of the backward pass (weight gradients)
     _main_stream = None                                             # the stream the backward itself runs on (set when _s2 is used)
     _use_side = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # diagnostic switch: "0" keeps the backward on one stream
+    _fused_stats = os.environ.get("DDPM_BN_FUSED", "0") == "1"     # BatchNorm statistics summed in the 3x3 convolution's epilogue
     _gall = ()          # gradient tensors this backward allocated itself (not slices of an averager's buffer)
     _gstate = None      # three device floats: largest |incoming gradient|, the backward's power-of-two scale, its inverse
 
@@ -89,16 +90,25 @@ class TrainMixin:
         dev = out.buf.device
         raw = V(torch.empty((b, h, w, cout), device=dev, dtype=torch.float32))
         bias = self.T(conv_key + ".bias")
+        mean = torch.empty(cout, device=dev, dtype=torch.float32)
+        invstd = torch.empty(cout, device=dev, dtype=torch.float32)
+        stat_rows = b * h * w
+        global_stats = self.sync_bn and _dist_active()
+        fused = self._fused_stats and first is None and not global_stats
         if first is not None:
             ep = Epilogue(None, _ptr(bias), None, None)
             call("ddpm_conv3x3_first_fwd", _ptr(first), _ptr(self.T(conv_key + ".weight")), C.byref(ep), ACT_NONE, raw.ptr, b,
                  first.shape[1], h, w, cout, raw.ld, _stream())
+        elif fused:
+            # the convolution's epilogue leaves the partial sums of the batch statistics: no separate pass over `raw`
+            nblk = self.conv3x3_stats(src, self.packed_conv3(conv_key), cout, raw, bias, self._workspace(dev))
+            call("ddpm_bn_stats_from_partials", _ptr(self._workspace(dev)), nblk, stat_rows, cout, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
+                 _ptr(self.T(bn_key + ".running_mean")), _ptr(self.T(bn_key + ".running_var")), _stream())
         else:
             self.conv3x3(src, self.packed_conv3(conv_key), cout, raw, None, bias)
-        mean = torch.empty(cout, device=dev, dtype=torch.float32)
-        invstd = torch.empty(cout, device=dev, dtype=torch.float32)
-        stat_rows = b * h * w
-        if self.sync_bn and _dist_active():
+        if fused:
+            pass
+        elif global_stats:
             # global-batch statistics: this rank's sums are all-reduced, then finalised on every rank. Every rank
             # holds the same number of samples (the batch axis is cut evenly), so the global row count needs no exchange.
             from . import parallel

@@ -230,6 +230,16 @@ typedef struct ddpm_epilogue {
 int ddpm_conv3x3_fwd(const ddpm_conv_desc* d, const float* src1, const float* src2,
                      const float* w_packed, const ddpm_epilogue* ep, float* out, void* stream);
 
+/* ddpm_conv3x3_fwd that also leaves the partial sums of train-mode BatchNorm statistics over the values it writes
+ * (what ddpm_bn_partials would compute from `out`): the 3x3 kernel's epilogue sums them while they are in registers
+ * (16 values at a time in fp32, those sums in float64), which saves the statistics' own pass over the tensor; shapes
+ * that kernel does not take (at most 32 output channels, two sources, very wide images) run the convolution and then
+ * ddpm_bn_partials. Finish with ddpm_bn_stats_from_partials(partial, *nblocks, batch*in_h*in_w, cout, ...). Replaces
+ * nn.Conv2d + the reduction of nn.BatchNorm2d in training, first-iteration/unet.py:16-17,
+ * second-iteration/unet.py:16-17,24-25,30-33. */
+int ddpm_conv3x3_fwd_stats(const ddpm_conv_desc* d, const float* src1, const float* src2, const float* w_packed,
+                           const ddpm_epilogue* ep, float* out, double* partial, int* nblocks, void* stream);
+
 /* 1x1. w_packed from ddpm_pack_conv1x1 (rows = cout, cin = c1+c2). Replaces the query/key/value projections
  * (second-iteration/unet.py:45-47,52-57) as ONE GEMM with cout = 2*(C/8) + C. */
 int ddpm_conv1x1_fwd(const ddpm_conv_desc* d, const float* src1, const float* src2,
@@ -326,6 +336,15 @@ int64_t ddpm_reduce_workspace_doubles(int c);
 int ddpm_bn_stats(const float* x, int ldx, int64_t rows, int c, float eps, float momentum,
                   double* workspace, float* mean, float* invstd, float* running_mean,
                   float* running_var, void* stream);
+
+/* The two halves of ddpm_bn_stats as separate calls: ddpm_bn_partials leaves per-block partial sums
+ * ([block][sum | sum of squares][c] doubles, *nblocks blocks, at most 1024: `partial` holds
+ * ddpm_reduce_workspace_doubles(c) doubles) and ddpm_bn_stats_from_partials finishes them in float64 in block order
+ * (mean, invstd, running statistics, as ddpm_bn_stats). ddpm_conv3x3_fwd_stats (below, with the convolutions) is the
+ * producer they exist for: nn.Conv2d followed by nn.BatchNorm2d in train mode, second-iteration/unet.py:16-21. */
+int ddpm_bn_partials(const float* x, int ldx, int64_t rows, int c, double* partial, int* nblocks, void* stream);
+int ddpm_bn_stats_from_partials(const double* partial, int nblocks, int64_t rows, int c, float eps, float momentum,
+                                float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
 
 /* ddpm_bn_stats without a workspace argument and without any allocation. No counterpart in the
  * reference: it exists for callers that cannot allocate device memory (code under HIP graph

@@ -167,6 +167,42 @@ def test_conv3x3(case):
     assert_close(from_nhwc(out), conv_ref(x, w, None, scale, shift, res, temb, act), TOL, f"conv3x3 {case}")
 
 
+@pytest.mark.parametrize("case", [(2, 28, 28, 64, 64), (3, 14, 14, 128, 96), (1, 30, 30, 64, 128), (5, 7, 7, 256, 512), (2, 9, 5, 16, 40),
+                                  (2, 8, 8, 8, 32), (300, 8, 8, 64, 64)])
+def test_conv3x3_with_batchnorm_statistics(case):
+    """ddpm_conv3x3_fwd_stats: the same output as ddpm_conv3x3_fwd, bit for bit, and batch statistics finished from the
+    partial sums its epilogue leaves that equal ddpm_bn_stats over that output (fp32 sums over 16 values, then float64,
+    against float64 throughout: 1e-6 of the value), ragged last tiles, a partly empty column block and the generic
+    kernel's shapes (32 output channels) included; running statistics follow momentum 0.1 with the unbiased variance."""
+    B, H, W, ci, co = case
+    x, w, bias = rnd((B, ci, H, W), 21), rnd((co, ci, 3, 3), 22, (9 * ci) ** -0.5), rnd((co,), 23) + 0.5
+    xd, wd, bd = to_nhwc(x), w.cuda().contiguous(), bias.cuda()
+    wp = torch.empty(packed_floats(9, co, ci), device="cuda")
+    call("ddpm_pack_conv3x3", P(wd), co, ci, 0, P(wp), stream())
+    d = ConvDesc(batch=B, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=0, ldr=0, out_h=H, out_w=W)
+    ep = Epilogue(None, P(bd), None, None)
+    ref_out = torch.empty((B, H, W, co), device="cuda")
+    call("ddpm_conv3x3_fwd", C.byref(d), P(xd), None, P(wp), C.byref(ep), P(ref_out), stream())
+    out = torch.full((B, H, W, co), float("nan"), device="cuda")
+    from diffusion_model_amd._lib import lib
+    ws = torch.full((int(lib().ddpm_reduce_workspace_doubles(max(co, 64))),), float("nan"), dtype=torch.float64, device="cuda")
+    nblk = C.c_int(0)
+    call("ddpm_conv3x3_fwd_stats", C.byref(d), P(xd), None, P(wp), C.byref(ep), P(out), P(ws), C.byref(nblk), stream())
+    assert torch.equal(out, ref_out)
+    assert 0 < nblk.value <= 1024
+    rows = B * H * W
+    got = [torch.empty(co, device="cuda") for _ in range(2)] + [torch.full((co,), 0.25, device="cuda"), torch.full((co,), 2.0, device="cuda")]
+    call("ddpm_bn_stats_from_partials", P(ws), nblk.value, rows, co, 1e-5, 0.1, *[P(t) for t in got], stream())
+    want = [torch.empty(co, device="cuda") for _ in range(2)] + [torch.full((co,), 0.25, device="cuda"), torch.full((co,), 2.0, device="cuda")]
+    ws2 = torch.empty_like(ws)
+    call("ddpm_bn_stats", P(ref_out), co, rows, co, 1e-5, 0.1, P(ws2), *[P(t) for t in want], stream())
+    for g, wnt, name in zip(got, want, ("mean", "invstd", "running_mean", "running_var")):
+        assert_close(g.cpu(), wnt.cpu(), 1e-6, f"{name} {case}")
+    flat = from_nhwc(ref_out).double().transpose(0, 1).reshape(co, -1)
+    assert_close(got[0].cpu(), flat.mean(1), 2e-6, "mean against torch")
+    assert_close(got[1].cpu(), 1.0 / torch.sqrt(flat.var(1, unbiased=False) + 1e-5), 2e-6, "invstd against torch")
+
+
 def test_conv3x3_two_sources_and_strided_output():
     """Input = channel concat of two tensors with their own pixel strides; output into a wider buffer."""
     B, H, W, c1, c2, co = 2, 12, 10, 24, 40, 48

@@ -125,6 +125,30 @@ def test_gradients_follow_the_loss_scale_exactly(factor):
         assert (got - ref).abs().max().item() <= 2e-6 * scale + 1e-9, k
 
 
+def test_train_forward_with_statistics_from_the_conv_epilogue():
+    """DDPM_BN_FUSED=1 (here: the engine's switch set directly): batch statistics summed in the 3x3 convolution's epilogue
+    instead of in their own pass. Full-width second-iteration UNet: the train-mode prediction, every running statistic and
+    the parameter gradients agree with the separate pass to fp32 rounding."""
+    U = pkg.make_unet_class(2)
+    x, t = seeded_tensor((4, 1, 28, 28), 91, "x").cuda(), seeded_ints((4,), 1000, 91, "t").cuda()
+    res = []
+    for fused in (False, True):
+        m = U(1, 1, 64, 128)
+        m.load_state_dict(seeded_state_dict(m.state_dict(), 19))
+        m = m.cuda().train()
+        m._engine._fused_stats = fused
+        out = m(x, t)
+        out.square().mean().backward()
+        res.append((out.detach().cpu(), {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if "running_" in k},
+                    {k: p.grad.cpu() for k, p in m.named_parameters()}))
+    assert_close(res[1][0], res[0][0], 2e-6, "train-mode prediction")
+    for k, v in res[0][1].items():
+        assert_close(res[1][1][k], v, 1e-6, k)
+    for k, g in res[0][2].items():
+        scale = g.abs().max().item()
+        assert (res[1][2][k] - g).abs().max().item() <= 2e-3 * scale + 5e-6, k
+
+
 def test_grad_needs_train_mode_and_no_input_grad():
     m = build(1, 1).eval()
     x = torch.zeros(1, 1, 16, 16, device="cuda")
