@@ -1,5 +1,5 @@
 // Timestep / label conditioning: sinusoidal embedding, then the four time Linears (plus the label
-// Embedding and four label Linears when labels are given). One workgroup per (sample, Linear).
+// Embedding and four label Linears when labels are given). One workgroup per (four samples, Linear).
 #include <cmath>
 
 #include "common.h"
@@ -23,14 +23,23 @@ struct EmbedDev {
     float log_step;  // fp32: log(10000) / (half - 1)
 };
 
+// A workgroup takes kSamples consecutive samples of one Linear, so that a weight row fetched from L2 serves all of them
+// (one sample per workgroup re-read the 1 MB of weights for every sample: 60 us at batch 512, all of it L2 traffic).
+constexpr int kSamples = 4;
+
 __global__ __launch_bounds__(256) void time_embed_kernel(const EmbedDev a) {
-    __shared__ float emb[kMaxEmb];
-    __shared__ float lemb[kMaxEmb];
-    const int b = blockIdx.x, which = blockIdx.y;
+    __shared__ float emb[kSamples][kMaxEmb];
+    __shared__ float lemb[kSamples][kMaxEmb];
+    __shared__ int bad[kSamples];
+    const int b0 = blockIdx.x * kSamples, which = blockIdx.y;
+    const int ns = min(kSamples, a.batch - b0);
     const int E = a.emb_dim, half = E >> 1;
-    const float tv = a.t_is_float ? static_cast<const float*>(a.t)[b]
-                                  : static_cast<float>(static_cast<const int64_t*>(a.t)[b]);
-    for (int i = threadIdx.x; i < 2 * half; i += blockDim.x) {
+    const bool has_label = a.n_labels > 0;
+    for (int idx = threadIdx.x; idx < ns * 2 * half; idx += blockDim.x) {
+        const int s = idx / (2 * half), i = idx - s * 2 * half;
+        const int b = b0 + s;
+        const float tv = a.t_is_float ? static_cast<const float*>(a.t)[b]
+                                      : static_cast<float>(static_cast<const int64_t*>(a.t)[b]);
         const int k = i < half ? i : i - half;
         // frequency exp(-k * log_step): the exponent is formed in fp32 as the reference does; the
         // exponential itself is taken in double and rounded once.
@@ -38,16 +47,19 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const EmbedDev a) {
         const float freq = static_cast<float>(exp(static_cast<double>(ex)));
         const float arg = tv * freq;
         const float v = i < half ? sinf(arg) : cosf(arg);
-        emb[i] = v;
+        emb[s][i] = v;
         if (which == 0 && a.emb_out) a.emb_out[static_cast<int64_t>(b) * E + i] = v;
     }
-    const bool has_label = a.n_labels > 0;
-    bool bad_label = false;
     if (has_label) {
-        const int64_t cls = a.y[a.n_labels == 1 ? 0 : b];
-        bad_label = cls < 0 || cls >= a.n_classes;      // never dereferenced: the outputs of this sample become NaN
-        if (!bad_label)
-            for (int i = threadIdx.x; i < E; i += blockDim.x) lemb[i] = a.label_table[cls * E + i];
+        for (int idx = threadIdx.x; idx < ns * E; idx += blockDim.x) {
+            const int s = idx / E, i = idx - s * E;
+            const int64_t cls = a.y[a.n_labels == 1 ? 0 : b0 + s];
+            const bool bad_label = cls < 0 || cls >= a.n_classes;      // never dereferenced: the outputs of this sample become NaN
+            lemb[s][i] = bad_label ? 0.f : a.label_table[cls * E + i];
+            if (i == 0) bad[s] = bad_label ? 1 : 0;
+        }
+    } else if (threadIdx.x < kSamples) {
+        bad[threadIdx.x] = 0;
     }
     __syncthreads();
     const int C = a.ch[which];
@@ -55,19 +67,47 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const EmbedDev a) {
     const float* bias = a.b[which];
     const float* lw = a.lw[which];
     const float* lb = a.lb[which];
-    float* out = a.out[which] + static_cast<int64_t>(b) * C;
-    for (int co = threadIdx.x; co < C; co += blockDim.x) {
-        const float* row = w + static_cast<int64_t>(co) * E;
-        float acc = 0.f;
-        for (int i = 0; i < 2 * half; ++i) acc += row[i] * emb[i];
-        acc += bias[co];
-        if (has_label) {
-            const float* lrow = lw + static_cast<int64_t>(co) * E;
-            float l = 0.f;
-            for (int i = 0; i < E; ++i) l += lrow[i] * lemb[i];
-            acc += l + lb[co];
+    // One output channel per thread; its weight row is read as 16-byte pieces, eight in flight, and added in channel
+    // order for every sample (the sum's order, and with it the result's bits, does not depend on how the row is fetched
+    // or on how many samples share it).
+    const bool vec = (E & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (!has_label || (reinterpret_cast<uintptr_t>(lw) & 15) == 0);
+    auto dot = [&](const float* __restrict__ row, const float (*x)[kMaxEmb], int n, float (&acc)[kSamples]) {
+#pragma unroll
+        for (int s = 0; s < kSamples; ++s) acc[s] = 0.f;
+        int i = 0;
+        if (vec) {
+            for (; i + 32 <= n; i += 32) {
+                float4 r[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) r[q] = *reinterpret_cast<const float4*>(row + i + 4 * q);
+#pragma unroll
+                for (int s = 0; s < kSamples; ++s)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        acc[s] += r[q].x * x[s][i + 4 * q];
+                        acc[s] += r[q].y * x[s][i + 4 * q + 1];
+                        acc[s] += r[q].z * x[s][i + 4 * q + 2];
+                        acc[s] += r[q].w * x[s][i + 4 * q + 3];
+                    }
+            }
         }
-        out[co] = bad_label ? __builtin_nanf("") : acc;
+        for (; i < n; ++i) {
+            const float rv = row[i];
+#pragma unroll
+            for (int s = 0; s < kSamples; ++s) acc[s] += rv * x[s][i];
+        }
+    };
+    for (int co = threadIdx.x; co < C; co += blockDim.x) {
+        float acc[kSamples], l[kSamples];
+        dot(w + static_cast<int64_t>(co) * E, emb, 2 * half, acc);
+        if (has_label) dot(lw + static_cast<int64_t>(co) * E, lemb, E, l);
+#pragma unroll
+        for (int s = 0; s < kSamples; ++s) {
+            if (s >= ns) continue;
+            float v = acc[s] + bias[co];
+            if (has_label) v += l[s] + lb[co];
+            a.out[which][static_cast<int64_t>(b0 + s) * C + co] = bad[s] ? __builtin_nanf("") : v;
+        }
     }
 }
 
@@ -128,6 +168,6 @@ extern "C" int ddpm_time_embed(const ddpm_embed_args* a, void* stream) {
         d.out[k] = a->out[k];
     }
     d.log_step = log_step_for(a->emb_dim);
-    time_embed_kernel<<<dim3(a->batch, 4), 256, 0, ddpm::as_stream(stream)>>>(d);
+    time_embed_kernel<<<dim3((a->batch + kSamples - 1) / kSamples, 4), 256, 0, ddpm::as_stream(stream)>>>(d);
     return ddpm::check_launch("time_embed_kernel");
 }
