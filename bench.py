@@ -440,6 +440,7 @@ class Job:
             "config": cfg,
             "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(kernel_peak(dom[0]), 1),
                          "unit": "TFLOP/s", "frac": round(achieved / kernel_peak(dom[0]), 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "x_fp32_matrix_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 3),   # against v_mfma_f32_32x32x2_f32's 157.3 TFLOP/s, the fp32 ceiling the split arithmetic replaces
                          "sustained_peak": (round(arith["sustained"] / arith["products"], 1) if arith else None),
                          "sustained_peak_note": (f"a loop of nothing but independent {arith['inst']} ({arith['probe']}) sustains "
                                                  f"{arith['sustained'] / 1e3:.2f} PFLOP/s on this chip (1.6-1.8 GHz under that load, not the 2.4 GHz "
