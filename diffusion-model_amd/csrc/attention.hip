@@ -284,6 +284,7 @@ using ddpm::conv::mfma16;
 #endif
 template <int DQ, int QB, int NCT, bool F16>
 __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnParams p) {
+    if constexpr (F16) ddpm::conv::fp16_saturate();
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     constexpr int NPL = F16 ? 2 : 3;            // operand planes
     constexpr int CS = 32 * NCT;
@@ -595,6 +596,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
 // same order per query as the kernel above: the results are bit-identical.
 template <int DQ, int NCT, int NW, bool F16>
 __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const AttnParams p) {
+    if constexpr (F16) ddpm::conv::fp16_saturate();
     const dim3 bid = ddpm::xcd_block();
     constexpr int NPL = F16 ? 2 : 3;    // operand planes
     constexpr int NPR = F16 ? 3 : 6;    // MFMAs per fragment pair

@@ -60,6 +60,7 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
 template <int NB0, int NB1, bool F16>   // column blocks of the waves of the first / second column half
 __global__ __launch_bounds__(kThreads, 1) void conv1x1_resident_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];   // [chunk][column block][plane][lane][16 B]
+    if constexpr (F16) fp16_saturate();
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -490,6 +491,7 @@ __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned cha
 template <int NB0, int NB1, bool F16>
 __global__ __launch_bounds__(kThreads, 1) void conv1x1_slab_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];   // [2][chunk of the slab][block of the tile][plane][lane][16 B]
+    if constexpr (F16) fp16_saturate();
     constexpr int NBT = NB0 + NB1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -125,14 +125,22 @@ static __device__ __forceinline__ void split_store(const f32x4 v, unsigned char*
 // ah*bh + (ah*bl + al*bh) * 2^-11: the hi*hi products accumulate in one MFMA accumulator, the two cross products in
 // a second one that is scaled and added at the end; the dropped al*bl term is below 2^-22 of a*b, zero on average.
 // The fp16 MFMA does not lose bits when it accumulates the way the bf16 one does (measured: no drift over 9216
-// like-signed terms), so no master accumulator is needed. Operands must stay below 65504 in magnitude; values
-// below 2^-14 lose relative (not absolute) precision.
+// like-signed terms), so no master accumulator is needed. Operands beyond 65504 in magnitude are clipped to +-65536
+// (fp16_saturate below); values below 2^-14 lose relative (not absolute) precision.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float kLoScale = 2048.0f;
 constexpr float kLoInv = 1.0f / 2048.0f;
 constexpr int XROW_F16 = 80;   // LDS bytes per tile row: two planes of 16 fp16 and 16 bytes of padding (conflict-free 16-byte reads)
+
+// MODE.FP16_OVFL = 1 for the calling wave (the MODE register is per-wave state, set afresh at every launch): a
+// float -> fp16 conversion that overflows gives +-65504 instead of infinity, true infinities and NaNs pass through
+// (tools/probe/fp16_ovfl.hip). Every kernel that forms fp16 pairs calls this first, so that an operand beyond fp16's
+// range is clipped to +-65536 (hi = 65504, remainder 65504 / 2048) instead of turning into inf - inf = NaN inside
+// the matrix instructions: an untrained network's samples, which grow to 1e7 over a 1000-step loop, stay finite as
+// they do in fp32.
+static __device__ __forceinline__ void fp16_saturate() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
 
 static __device__ __forceinline__ void split2_pair(const f32x2 v, unsigned& hi, unsigned& lo) {
     const f16x2 h = __builtin_convertvector(v, f16x2);

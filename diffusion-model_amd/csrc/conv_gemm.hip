@@ -327,6 +327,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
 // after the last step; no fold.
 template <int BN, int MODE, bool DUAL, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p) {
+    if constexpr (F16) fp16_saturate();
     constexpr int TN = BN / 64;               // 32-column MFMA tiles per wave (2 x 2 waves)
     constexpr int NB = (BN * 6 + 255) / 256;  // 16-byte weight pieces per thread and step
 
@@ -856,6 +857,7 @@ struct SplitPack {
 };
 
 __global__ void pack_split_kernel(const SplitPack a) {
+    if (a.f16) fp16_saturate();
     const int64_t total = static_cast<int64_t>(a.taps) * a.kc16 * a.nbp * 512;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
@@ -890,6 +892,7 @@ __device__ __forceinline__ float qkv_weight(const QkvPack& a, int n, int ch) {
 }
 
 __global__ void pack_qkv_kernel(const QkvPack a) {
+    if (a.f16) fp16_saturate();
     const int lq = 2 * a.dqp + a.c;
     const int64_t t0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x, stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     if (a.split) {
@@ -954,6 +957,7 @@ struct SplitPackBatch {
 };
 __global__ void pack_split_batch_kernel(const SplitPackBatch b) {
     const SplitPack& a = b.item[blockIdx.y];
+    if (a.f16) fp16_saturate();
     const int64_t total = static_cast<int64_t>(a.taps) * a.kc16 * a.nbp * 512;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {

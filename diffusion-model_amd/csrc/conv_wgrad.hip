@@ -274,6 +274,7 @@ __device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* d
 template <int MODE, int PAIR, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams p) {
     static_assert(PAIR == 0 || MODE == WG_CONV3, "two taps per tile exist for the 3x3 convolution only");
+    if constexpr (F16) ddpm::conv::fp16_saturate();
     constexpr int BT = 128;
     constexpr int NPL = F16 ? 2 : 3;      // operand planes
     constexpr int F4R = BT / 4;           // float4 per tile row
