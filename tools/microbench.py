@@ -100,6 +100,33 @@ def main():
         x, e, z, o = (torch.randn(n, device=dev) for _ in range(4))
         t = timeit(lambda: call("ddpm_reverse_step", P(x), P(e), None, 0.0, P(z), 1.01, 0.02, 0.1, P(o), n, S()), iters)
         print(f"reverse_step n={n}: {t*1e6:.1f} us  {16.0*n/t/1e9:.1f} GB/s")
+    elif kind == "bn":
+        import hashlib
+        B, H, W, c = a[:4]
+        iters = a[4] if len(a) > 4 else 30
+        rows = B * H * W
+        torch.manual_seed(0)
+        x, dy, res = (torch.randn(rows, c, device=dev) for _ in range(3))
+        w, b = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.1
+        temb = torch.randn(B, c, device=dev)
+        mean, invstd, rm, rv = (torch.zeros(c, device=dev) for _ in range(4))
+        ws = torch.empty(8192 * c, dtype=torch.float64, device=dev)
+        out, dx, dres = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        sums, dw, db, dcb = torch.empty(2 * c, device=dev), torch.empty(c, device=dev), torch.empty(c, device=dev), torch.empty(c, device=dev)
+        mb = rows * c * 4 / 1e6
+        digest = lambda *ts: hashlib.sha1(b"".join(t.cpu().numpy().tobytes() for t in ts)).hexdigest()[:12]
+        t = timeit(lambda: call("ddpm_bn_stats", P(x), c, rows, c, 1e-5, 0.1, P(ws), P(mean), P(invstd), P(rm), P(rv), S()), iters)
+        print(f"bn stats   {rows}x{c}: {t*1e6:6.1f} us  {mb/t/1e6:.2f} TB/s ({mb:.0f} MB per tensor)  {digest(mean, invstd)}")
+        for act, r in ((2, None), (2, res)):
+            k = 2 + (r is not None)
+            t = timeit(lambda: call("ddpm_bn_apply_fwd", P(x), c, P(mean), P(invstd), P(w), P(b), P(r), c, P(temb), act, P(out), c, B, H * W, c,
+                                    S()), iters)
+            print(f"bn apply   {rows}x{c} res={r is not None}: {t*1e6:6.1f} us  {k*mb/t/1e6:.2f} TB/s  {digest(out)}")
+            t = timeit(lambda: call("ddpm_bn_bwd", P(x), c, P(dy), c, P(r), c, P(mean), P(invstd), P(w), P(b), act, rows, c, P(ws), P(sums), P(dw),
+                                    P(db), 0, P(dx), c, P(dres) if r is not None else None, c, P(dcb), S()), iters)
+            k = 2 * (2 + (r is not None)) + 1 + (r is not None)
+            print(f"bn bwd     {rows}x{c} res={r is not None}: {t*1e6:6.1f} us  {k*mb/t/1e6:.2f} TB/s (sums pass + apply pass)  "
+                  f"{digest(dx, dw, db, dcb, *([dres] if r is not None else []))}")
     else:
         sys.exit(__doc__)
 
