@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
             return (v < 2 ? &sA[set ^ 1][0] : &sB[set ^ 1][0]) + (row0 + RSTEP * (v & 1)) * XROWB + c4 * 8;
         };
 #ifndef DDPM_WG_ABLATE
-#define DDPM_WG_ABLATE 0   // diagnostic builds only: 1 no split stages, 2 no global loads, 4 no barrier, 8 no matrix ops
+#define DDPM_WG_ABLATE 0   // diagnostic builds only: 1 no split stages, 2 no global loads, 4 no barrier, 8 no matrix ops, 16 no fragment reads (fp16 pair), 32 no atomic adds
 #endif
         if constexpr (F16) {
             // split state of the four float4 of step + 1 (two of each operand): eight stages, one behind each of the
@@ -480,11 +480,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
             auto mfma = [&](int k) {
                 const int t = k >> 2, i = (k >> 1) & 1, j = k & 1;
                 const f16x8 av = __builtin_bit_cast(f16x8, a[i][t == 0 ? 1 : 0]), bv = __builtin_bit_cast(f16x8, b[j][t == 1 ? 1 : 0]);
-                if (t < 2) master[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, master[i][j], 0, 0, 0);   // lo*hi, hi*lo
+                if (DDPM_WG_ABLATE & 8) master[i][j][k & 15] += static_cast<float>(av[0]) + static_cast<float>(bv[1]);
+                else if (t < 2) master[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, master[i][j], 0, 0, 0);   // lo*hi, hi*lo
                 else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[i][j], 0, 0, 0);               // hi*hi
             };
-            reads(1, 0);
-            reads(0, 1);
+            if (!(DDPM_WG_ABLATE & 16)) {
+                reads(1, 0);
+                reads(0, 1);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        a[q][pl] = __builtin_bit_cast(s16x8, areg[set][q]);
+                        b[q][pl] = __builtin_bit_cast(s16x8, breg[set][pl]);
+                    }
+            }
             if (!(DDPM_WG_ABLATE & 2)) load_global(set);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -589,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = (PAIR == 2 ? 0 : m0 + wm * 64) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < p.m_total) atomicAdd(outp + static_cast<int64_t>(m) * p.n_total + n, master[i][j][e]);
+                if (m < p.m_total && (!(DDPM_WG_ABLATE & 32) || master[i][j][e] == 1.2345f)) atomicAdd(outp + static_cast<int64_t>(m) * p.n_total + n, master[i][j][e]);
             }
     }
 }
