@@ -19,9 +19,10 @@ constexpr int kMaxPixels = 64;
 constexpr int kSLD = kMaxPixels + 1;   // score row stride (floats)
 
 // Where these kernels beat the tiled ones (measured at 512 channels, batch 256-512): up to 32 pixels both
-// ways, 4-7x; the backward up to 49 pixels when a workgroup may take the whole LDS, 1.45x; at 64 pixels
-// the tiled MFMA kernels win both ways.
-constexpr int kFwdPixels = 32, kBwdPixels = 49;
+// ways, 4-7x; the backward up to 64 pixels when a workgroup may take the whole LDS (49 pixels: 130 against
+// 300 us at batch 256; 64 pixels: 400 against 595 us at batch 512); the forward at 49 and 64 pixels is
+// faster on the tiled kernels (49 against 62 us, 112 against 200 us).
+constexpr int kFwdPixels = 32, kBwdPixels = 64;
 int lds_limit(int n) { return (n <= 32 ? 80 : 160) * 1024; }   // small maps: two workgroups per CU
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -53,14 +54,27 @@ __device__ __forceinline__ void stage_qk(const float* __restrict__ rows, int n, 
 }
 
 // dst[i][0..cc) = scale * src[i][0..cc) for the n rows of one sample
+// (a workgroup is alone on its CU, one wave per SIMD: four loads are requested before the first is used, or every
+// iteration would wait out a whole memory latency)
 __device__ __forceinline__ void stage_rows(const float* __restrict__ src, int64_t ld, int n, int cc, float scale, float* dst, int dld) {
-    const int c4 = cc >> 2;
-    for (int idx = threadIdx.x; idx < n * c4; idx += 256) {
-        const int i = idx / c4, ch = (idx - i * c4) << 2;
-        f32x4 v = *reinterpret_cast<const f32x4*>(src + i * ld + ch);
+    const int c4 = cc >> 2, total = n * c4;
+    for (int idx0 = threadIdx.x; idx0 < total; idx0 += 4 * 256) {
+        f32x4 v[4];
+        int i[4], ch[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= scale;
-        *reinterpret_cast<f32x4*>(dst + i * dld + ch) = v;
+        for (int u = 0; u < 4; ++u) {
+            const int idx = idx0 + u * 256;
+            i[u] = idx / c4;
+            ch[u] = (idx - i[u] * c4) << 2;
+            if (idx < total) v[u] = *reinterpret_cast<const f32x4*>(src + i[u] * ld + ch[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (idx0 + u * 256 >= total) break;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[u][e] *= scale;
+            *reinterpret_cast<f32x4*>(dst + i[u] * dld + ch[u]) = v[u];
+        }
     }
 }
 
@@ -109,7 +123,21 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const SmallFwd p) {
         for (int idx = tid; idx < n * c4; idx += 256) {
             const int i = idx / c4, cl = (idx - i * c4) << 2, ch = c0 + cl;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int j = 0; j < n; ++j) {
+            int j = 0;
+            for (; j + 3 < n; j += 4) {
+                float w[4];
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    w[u] = sS[i * kSLD + j + u];
+                    v[u] = *reinterpret_cast<const f32x4*>(sV + (j + u) * cc + cl);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[u], v[u][e], acc[e]);
+            }
+            for (; j < n; ++j) {
                 const float w = sS[i * kSLD + j];
                 const f32x4 v = *reinterpret_cast<const f32x4*>(sV + j * cc + cl);
 #pragma unroll
@@ -157,43 +185,85 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const SmallBwd p) {
         sT[i * kSLD + j] = 0.f;
     }
     const int grp = tid >> 3, l8 = tid & 7, c4 = cc >> 2;
-    const int pairs = n * n, pairs_up = (pairs + 31) & ~31;
+    const int pairs = n * n;
+    const int nb4 = (n + 3) >> 2, blocks = nb4 * nb4, blocks_up = (blocks + 31) & ~31;
     for (int c0 = 0; c0 < c; c0 += cc) {
         __syncthreads();
         stage_rows(rows + 2 * dq + c0, p.lq, n, cc, 1.f, sV, vld);
         stage_rows(p.dy + pix0 * p.ldd + c0, p.ldd, n, cc, g, sG, vld);
         __syncthreads();
-        // dP[i][j] += (gamma dY)[i] . V[j] over this chunk: eight lanes per pair, each over every eighth
-        // group of four channels; the pair -> lane map is the same in every chunk, so lane 0 of the group
-        // owns the running sum
-        for (int pair = grp; pair < pairs_up; pair += 32) {
-            const bool live = pair < pairs;
-            const int i = live ? pair / n : 0, j = live ? pair - i * n : 0;
-            float acc = 0.f;
-            for (int ch = l8 << 2; ch < cc; ch += 32) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(sG + i * vld + ch);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(sV + j * vld + ch);
-                acc = fmaf(a[0], v[0], acc);
-                acc = fmaf(a[1], v[1], acc);
-                acc = fmaf(a[2], v[2], acc);
-                acc = fmaf(a[3], v[3], acc);
-            }
-            acc += __shfl_xor(acc, 1);
-            acc += __shfl_xor(acc, 2);
-            acc += __shfl_xor(acc, 4);
-            if (live && l8 == 0) sT[i * kSLD + j] += acc;
-        }
-        // dV = P^T (gamma dY) for this chunk
-        for (int idx = tid; idx < n * c4; idx += 256) {
-            const int j = idx / c4, cl = (idx - j * c4) << 2;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int i = 0; i < n; ++i) {
-                const float w = sP[i * kSLD + j];
-                const f32x4 v = *reinterpret_cast<const f32x4*>(sG + i * vld + cl);
+        // dP[i][j] += (gamma dY)[i] . V[j] over this chunk: eight lanes per 4 x 4 block of (query, key) pairs, each over
+        // every eighth group of four channels, so that eight row reads feed 64 FMAs; the block -> lane map is the same
+        // in every chunk, so lane 0 of the group owns the running sums. Rows past n repeat row n - 1 and are dropped.
+        for (int blk = grp; blk < blocks_up; blk += 32) {
+            const bool live = blk < blocks;
+            const int bi = live ? blk / nb4 : 0, bj = live ? blk - bi * nb4 : 0;
+            const float* ga[4];
+            const float* va[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaf(w, v[e], acc[e]);
+            for (int u = 0; u < 4; ++u) {
+                ga[u] = sG + min(4 * bi + u, n - 1) * vld;
+                va[u] = sV + min(4 * bj + u, n - 1) * vld;
             }
-            *reinterpret_cast<f32x4*>(drows + static_cast<int64_t>(j) * p.lq + 2 * dq + c0 + cl) = acc;
+            float acc[4][4];
+#pragma unroll
+            for (int ui = 0; ui < 4; ++ui)
+#pragma unroll
+                for (int uj = 0; uj < 4; ++uj) acc[ui][uj] = 0.f;
+            for (int ch = l8 << 2; ch < cc; ch += 32) {
+                f32x4 a[4], v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = *reinterpret_cast<const f32x4*>(ga[u] + ch);
+                    v[u] = *reinterpret_cast<const f32x4*>(va[u] + ch);
+                }
+#pragma unroll
+                for (int ui = 0; ui < 4; ++ui)
+#pragma unroll
+                    for (int uj = 0; uj < 4; ++uj) {
+                        float t = acc[ui][uj];
+                        t = fmaf(a[ui][0], v[uj][0], t);
+                        t = fmaf(a[ui][1], v[uj][1], t);
+                        t = fmaf(a[ui][2], v[uj][2], t);
+                        t = fmaf(a[ui][3], v[uj][3], t);
+                        acc[ui][uj] = t;
+                    }
+            }
+#pragma unroll
+            for (int ui = 0; ui < 4; ++ui)
+#pragma unroll
+                for (int uj = 0; uj < 4; ++uj) {
+                    float t = acc[ui][uj];
+                    t += __shfl_xor(t, 1);
+                    t += __shfl_xor(t, 2);
+                    t += __shfl_xor(t, 4);
+                    const int i = 4 * bi + ui, j = 4 * bj + uj;
+                    if (live && l8 == 0 && i < n && j < n) sT[i * kSLD + j] += t;
+                }
+        }
+        // dV = P^T (gamma dY) for this chunk: a thread owns four keys x four channels
+        for (int idx = tid; idx < nb4 * c4; idx += 256) {
+            const int jb = idx / c4, cl = (idx - jb * c4) << 2;
+            int jj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) jj[u] = min(4 * jb + u, n - 1);
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < n; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sG + i * vld + cl);
+                float w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = sP[i * kSLD + jj[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[u][e] = fmaf(w[u], v[e], acc[u][e]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (4 * jb + u < n)
+                    *reinterpret_cast<f32x4*>(drows + static_cast<int64_t>(4 * jb + u) * p.lq + 2 * dq + c0 + cl) = acc[u];
         }
     }
     __syncthreads();

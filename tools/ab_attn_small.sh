@@ -1,9 +1,11 @@
 #!/bin/bash
-# A/B of the one-workgroup-per-sample attention against the tiled kernels at the bottleneck shapes.
+# Small-map attention (one workgroup per sample) on the bottleneck shapes: the shipped library against ablate_build/lib_as_old.so.
 set -o pipefail
-for shape in "256 49 512" "512 64 512" "256 9 512"; do
-  echo "== $shape tiled"; DDPM_ATTN_SMALL=0 timeout -k 10 100 python tools/microbench.py attn $shape 20 || exit 1
-  for kib in 80 160; do
-    echo "== $shape small, $kib KiB"; DDPM_ATTN_SMALL_LDS=$kib timeout -k 10 100 python tools/microbench.py attn $shape 20 || exit 1
+cd "$(dirname "$0")/.."
+for shape in "256 49 512" "256 9 512" "512 16 512" "512 64 512" "256 49 1024"; do
+  for lib in "" ablate_build/lib_as_old.so; do
+    echo "== ${lib:-shipped}"
+    if [ -n "$lib" ]; then export DDPM_LIB=$PWD/$lib; else unset DDPM_LIB; fi
+    timeout -k 10 60 python tools/microbench.py attn $shape 20 2>/dev/null || exit 1
   done
 done

@@ -81,7 +81,9 @@ def main():
         B, N, c = a[:3]
         iters = a[3] if len(a) > 3 else 10
         dq = max(8, c // 8)
+        torch.manual_seed(1)
         qkv = torch.randn(B, N, 2 * dq + c, device=dev) * 0.5
+        torch.manual_seed(0)
         x, dy = torch.randn(B, N, c, device=dev), torch.randn(B, N, c, device=dev)
         g = torch.full((1,), 0.5, device=dev)
         out, raw, lse = torch.empty_like(x), torch.empty_like(x), torch.empty(B, N, device=dev)
@@ -93,7 +95,9 @@ def main():
         dqkv, dg = torch.empty_like(qkv), torch.empty(1, device=dev)
         t = timeit(lambda: call("ddpm_attention_bwd", P(qkv), P(dy), c, P(raw), P(lse), P(g), P(ws), P(es), P(dqkv), P(dg), B, N, c, dq,
                                 S()), iters)
-        print(f"attn bwd B={B} N={N} C={c}: {t*1e6:.1f} us  {2.0*B*N*N*(3*dq+3*c)/t/1e12:.1f} TFLOP/s (algorithmic, no recompute)")
+        import hashlib
+        digest = hashlib.sha1(dqkv.cpu().numpy().tobytes() + out.cpu().numpy().tobytes()).hexdigest()[:12]
+        print(f"attn bwd B={B} N={N} C={c}: {t*1e6:.1f} us  {2.0*B*N*N*(3*dq+3*c)/t/1e12:.1f} TFLOP/s (algorithmic, no recompute)  outputs {digest}")
     elif kind == "step":
         n = a[0]
         iters = a[1] if len(a) > 1 else 50
