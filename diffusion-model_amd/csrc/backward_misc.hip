@@ -169,15 +169,15 @@ __global__ __launch_bounds__(kThreads) void first_wgrad_partial_kernel(const flo
     double v[36];
 #pragma unroll
     for (int e = 0; e < 36; ++e) v[e] = 0.0;
-    const int64_t rows = static_cast<int64_t>(batch) * h * w;
+    const unsigned rows = static_cast<unsigned>(batch) * h * w;       // below 2^31: checked by the caller (32-bit divisions below)
     if (l.active) {
-        for (int64_t r = static_cast<int64_t>(blockIdx.x) * l.rows_per_pass + l.roff; r < rows;
-             r += static_cast<int64_t>(gridDim.x) * l.rows_per_pass) {
-            const int xx = static_cast<int>(r % w);
-            const int yy = static_cast<int>((r / w) % h);
-            const int64_t b = r / (static_cast<int64_t>(w) * h);
-            const float* plane = x + (b * cin + ci) * h * w;
-            const float4 g = *reinterpret_cast<const float4*>(dy + r * ld + l.c4 * 4);
+        for (unsigned r = blockIdx.x * l.rows_per_pass + l.roff; r < rows; r += gridDim.x * l.rows_per_pass) {
+            const unsigned row = r / static_cast<unsigned>(w);
+            const int xx = static_cast<int>(r - row * w);
+            const unsigned b = row / static_cast<unsigned>(h);
+            const int yy = static_cast<int>(row - b * h);
+            const float* plane = x + (static_cast<int64_t>(b) * cin + ci) * h * w;
+            const float4 g = *reinterpret_cast<const float4*>(dy + static_cast<int64_t>(r) * ld + l.c4 * 4);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
@@ -361,6 +361,7 @@ extern "C" int ddpm_conv3x3_first_wgrad(const float* dy, int ldy, const float* x
                                         int w_, int cout, void* stream) {
     DDPM_REQUIRE(dy && x_nchw && workspace && dw && batch > 0 && cin > 0 && h > 0 && w_ > 0 && cout > 0);
     DDPM_REQUIRE((cout & 3) == 0 && cout <= 1024 && (ldy & 3) == 0 && ldy >= cout && ddpm::aligned16(dy));
+    DDPM_REQUIRE(static_cast<int64_t>(batch) * h * w_ < (1ll << 31));
     hipStream_t s = as_stream(stream);
     int nb = blocks_for(static_cast<int64_t>(batch) * h * w_, cout);
     for (int ci = 0; ci < cin; ++ci) {
