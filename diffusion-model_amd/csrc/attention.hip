@@ -23,6 +23,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KT = 32;  // keys per tile
+// In INFERENCE calls (no log-sum-exp wanted) the matrix kernels' running row maximum follows the scores only when a tile
+// exceeds it by more than this (natural-log units: probabilities stay below e^5.5 = 245, far inside fp32 and the fp16
+// pair). A softmax is the same for every shift, so the result is unchanged up to rounding, while the output
+// accumulators are rescaled on the first tiles only instead of whenever any row of the wave meets a larger score
+// (5-8 % of these calls). Training calls keep the exact maximum, and with it the bits the backward pass was tuned on.
+constexpr float kMaxSlack = 5.5f;
 
 __device__ __forceinline__ int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -351,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
                 if constexpr (F16) ox[qb][t][e] = 0.f;
             }
     float m_run[QB], l_run[QB];
+    const float slack = p.lse ? 0.f : kMaxSlack;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         m_run[qb] = -INFINITY;
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
 #pragma unroll
                 for (int e = 1; e < 16; ++e) mt = fmaxf(mt, s[qb][e]);
                 mt = fmaxf(mt, __shfl_xor(mt, 32));
-                const float m_new = fmaxf(m_run[qb], mt);
+                const float m_new = mt > m_run[qb] + slack ? mt : m_run[qb];       // (first tile: m_run = -inf, so m_new = mt)
                 const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * 1.4426950408889634f);   // 0 on the first tile
                 float ps = 0.f;
 #pragma unroll
@@ -659,6 +666,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
             if constexpr (F16) ox[t][e] = 0.f;
         }
     float m_run = -INFINITY, l_run = 0.f;
+    const float slack = p.lse ? 0.f : kMaxSlack;
 
     f32x4 kreg[KPT], vreg[VPT];
     // K and V rows come through a range-checked descriptor over the sample's [n][lq] block: rows past the last key
@@ -742,7 +750,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
             for (int e = 11; e < 16; ++e) mt = fmaxf(mt, s[e]);
             mt = fmaxf(mt, __shfl_xor(mt, 32));
         } else if constexpr (i == 3) {
-            m_new = fmaxf(m_run, mt);
+            m_new = mt > m_run + slack ? mt : m_run;                 // (first tile: m_run = -inf, so m_new = mt)
             alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);   // 0 on the first tile
             ps = 0.f;
         } else if constexpr (i < 20) {

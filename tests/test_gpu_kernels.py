@@ -433,6 +433,38 @@ def test_attention_large_logits_rescale():
     assert_close(out.cpu(), want, TOL, "attention rescale")
 
 
+@pytest.mark.parametrize("case", [(1, 1024, 128, 16), (1, 1024, 64, 8), (2, 300, 256, 32), (1, 784, 128, 16)])
+def test_attention_scores_that_rise_from_tile_to_tile(case):
+    """The matrix kernels let their running row maximum lag behind the scores by up to 5.5 before they rescale the output
+    accumulators. Here every query's scores rise by 0.5 ... 1.5 per tile of 32 keys (up to 48 at the last key), so that the
+    maximum lags, catches up every few tiles, and does so at different tiles for different queries; output, raw output
+    and log-sum-exp against float64, inference and training call."""
+    B, N, c, dq = case
+    dqp = (dq + 7) // 8 * 8
+    g = torch.Generator().manual_seed(21)
+    u = torch.randn(dq, generator=g)
+    u /= u.norm()
+    amp = 0.5 + torch.rand(B, N, 1, generator=g)                                    # per query: 0.5 ... 1.5 per tile
+    q = u * amp + 0.05 * torch.randn(B, N, dq, generator=g)
+    k = u * (torch.arange(N, dtype=torch.float32) / 32.0)[None, :, None] + 0.05 * torch.randn(B, N, dq, generator=g)
+    v, x = rnd((B, N, c), 3), rnd((B, N, c), 4)
+    qkv = torch.zeros((B, N, 2 * dqp + c))
+    qkv[..., :dq], qkv[..., dqp:dqp + dq], qkv[..., 2 * dqp:] = q, k, v
+    scores = torch.bmm(q.double(), k.double().transpose(1, 2))
+    raw_want = torch.bmm(torch.softmax(scores, dim=-1), v.double())
+    want = 0.8 * raw_want + x.double()
+    lse_want = torch.logsumexp(scores, dim=-1)
+    keep = [qkv.cuda(), x.cuda(), torch.full((1,), 0.8, device="cuda")]
+    out = torch.full((B, N, c), float("nan"), device="cuda")
+    call("ddpm_attention_fwd", P(keep[0]), P(keep[1]), c, P(keep[2]), P(out), c, None, None, None, B, N, c, dqp, stream())
+    assert_close(out.cpu(), want, TOL, f"rising scores, inference call {case}")
+    out2, raw, lse = torch.empty_like(out), torch.empty_like(out), torch.empty((B, N), device="cuda")
+    call("ddpm_attention_fwd", P(keep[0]), P(keep[1]), c, P(keep[2]), P(out2), c, P(raw), P(lse), None, B, N, c, dqp, stream())
+    assert_close(out2.cpu(), want, TOL, f"rising scores, training call {case}")
+    assert_close(raw.cpu(), raw_want, TOL, f"rising scores, raw output {case}")
+    assert_close(lse.cpu(), lse_want, TOL, f"rising scores, log-sum-exp {case}")
+
+
 def test_adam_step_argument_checks():
     """ddpm_adam_step through the raw C ABI: an empty list is a no-op, bad arguments return an error code."""
     from diffusion_model_amd import _lib
