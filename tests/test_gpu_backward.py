@@ -276,7 +276,7 @@ def test_time_embed_fwd_bwd(n_labels):
 @pytest.mark.parametrize("case", [(2, 49, 64, 8), (2, 196, 32, 4), (1, 784, 128, 16), (2, 64, 512, 64), (2, 100, 8, 1), (3, 33, 256, 32), (2, 196, 256, 32),
                                   (1, 1024, 128, 16), (1, 4096, 64, 8), (1, 4096, 128, 16),
                                   (2, 64, 1024, 128), (2, 49, 1024, 128), (1, 256, 1024, 128), (3, 16, 1024, 128),
-                                  # small maps: one workgroup per sample (forward up to 32 pixels, backward up to 49)
+                                  # small maps: one workgroup per sample (forward up to 32 pixels, backward up to 64)
                                   (5, 9, 512, 64), (3, 16, 512, 64), (2, 32, 512, 64), (4, 1, 64, 8), (3, 25, 32, 4), (2, 32, 8, 1), (3, 49, 512, 64)])
 def test_attention_bwd(case):
     B, N, c, dq = case

@@ -370,7 +370,7 @@ def test_pool_skip_and_add_temb(case):
                                   (2, 128, 128, 16), (3, 129, 128, 16), (2, 160, 256, 32), (2, 161, 192, 32), (1, 200, 160, 8), (2, 95 + 33, 320, 32),
                                   # 128 query channels: the bottleneck of a base_channels = 128 network (C = 1024)
                                   (2, 64, 1024, 128), (2, 49, 1024, 128), (1, 256, 1024, 128), (3, 16, 1024, 128),
-                                  # small maps: one workgroup per sample (forward up to 32 pixels, backward up to 49)
+                                  # small maps: one workgroup per sample (forward up to 32 pixels, backward up to 64)
                                   (5, 9, 512, 64), (3, 16, 512, 64), (2, 32, 512, 64), (4, 1, 64, 8), (3, 25, 32, 4), (2, 32, 8, 1), (3, 49, 512, 64)])
 def test_attention_fwd(case):
     B, N, c, dq = case
