@@ -323,6 +323,32 @@ def test_convT2x2_pad_crop(case):
     assert_close(from_nhwc(out), want, TOL, f"convT {case}")
 
 
+@pytest.mark.parametrize("case", [(80, 16, 16, 256, 128), (70, 16, 16, 64, 40), (21, 32, 32, 128, 64), (67, 16, 16, 192, 72), (130, 11, 13, 64, 64)])
+def test_convT2x2_many_rows(case):
+    """16384 input pixels and more with the output exactly twice the input (the shapes of the sampling and training
+    batches). Against torch, with a wider output row than cout (ldo), untouched padding columns, and bit for bit against
+    the same samples in small batches: a result must not depend on how a batch was cut."""
+    B, H, W, ci, co = case
+    x, w, b = rnd((B, ci, H, W), 1), rnd((ci, co, 2, 2), 2, ci ** -0.5), rnd((co,), 3)
+    want = F.conv_transpose2d(x, w, b, stride=2)
+    wp = torch.empty(packed_floats(1, 4 * co, ci), device="cuda")
+    call("ddpm_pack_convT2x2", P(w.cuda()), ci, co, P(wp), stream())
+    ldo = co + 8
+    out = torch.full((B, 2 * H, 2 * W, ldo), 7.0, device="cuda")
+    xd, bd = to_nhwc(x), b.cuda()
+    ep = Epilogue(None, P(bd), None, None)
+    d = ConvDesc(batch=B, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=ldo, act=0, ldr=0, out_h=2 * H, out_w=2 * W)
+    call("ddpm_convT2x2_fwd", C.byref(d), P(xd), P(wp), C.byref(ep), P(out), stream())
+    assert_close(from_nhwc(out[..., :co].contiguous()), want, TOL, f"convT, many rows {case}")
+    assert torch.all(out[..., co:] == 7.0)
+    cut = 8
+    small = torch.empty((cut, 2 * H, 2 * W, ldo), device="cuda")
+    for b0 in (0, B - cut):
+        d2 = ConvDesc(batch=cut, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=ldo, act=0, ldr=0, out_h=2 * H, out_w=2 * W)
+        call("ddpm_convT2x2_fwd", C.byref(d2), P(xd[b0:b0 + cut]), P(wp), C.byref(ep), P(small), stream())
+        assert torch.equal(small[..., :co], out[b0:b0 + cut, ..., :co]), f"convT {case}: batch of {B} against batch of {cut} at sample {b0}"
+
+
 @pytest.mark.parametrize("cin", [1, 3])
 def test_first_and_final_conv(cin):
     B, H, W, co = 3, 11, 13, 16
