@@ -1,22 +1,26 @@
 #!/usr/bin/env python3
 """Benchmark of the DDPM hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload both|train|sample|train_color|sample_64] [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--workload both|train|sample|train_color|sample_64|sample_c1] [--batch B]
 
 One "step" is one pass of the hot path over one batch of synthetic input:
   train  (BASELINE.json configs[1]): the body of the reference's training loop
          (first-iteration/main.py:65-87) -- noise + timestep draw, forward noising, UNet train-mode
          forward, eps-MSE, backward, Adam step, loss.item() -- second-iteration UNet (1,1,64,128),
-         1x28x28, batch 256 per GPU. value = train samples/s.
-  sample (BASELINE.json configs[2]): one ancestral denoising step at batch 512 per GPU (UNet eval
-         forward, noise draw, fused reverse-step kernel), third-iteration UNet, 1x32x32. The metric,
-         sampled images/s over the full T=1000-step loop, is B_total / (1000 * seconds per step); a
-         real DiffusionModel.sample() call (T=50 schedule) is timed next to it to show that the
-         call costs T times the step.
-The default (--workload both) measures BOTH halves of the metric, K timed steps each: the JSON
-line's top-level fields are the training half, its "sampling" object the sampling half.
-For N > 1 the batch axis is sharded (weak scaling: per-GPU batch fixed): no data-path collective for
-sampling; RCCL all-reduces of gradient buckets (launched while the backward is still running) per
+         1x28x28, batch 256 per GPU (weak scaling: the reference's loop at a larger global batch).
+         value = train samples/s.
+  sample (BASELINE.json configs[2]): ancestral sampling of a GLOBAL batch of 4096 images, third-iteration
+         UNet, 1x32x32, sharded over the N GPUs (strong scaling: 4096 / N images per GPU). Two measurements:
+         K timed denoising steps (UNet eval forward, noise draw, fused reverse-step kernel), and ONE real
+         DiffusionModel.sample() call over the full T = 1000 steps, wall clock, its ten stage copies to
+         the host included: value = sampled images/s = 4096 / that wall time.
+The default (--workload both) measures BOTH halves of the metric: the JSON line's top-level fields are
+the training half, its "sampling" object the sampling half. Each half also reports the same K steps in
+the full-range arithmetic (three bf16 planes per operand) beside the default fp16 pair ("full_range").
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; started as plain
+`python bench.py --gpus N` this script starts those N ranks itself, before anything touches a GPU. No
+data-path collective for sampling; RCCL all-reduces of gradient buckets (launched while the backward is
+still running) and of the BatchNorm sums (global-batch statistics: the reference's semantics) per
 training step. Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -24,10 +28,9 @@ import ctypes as C
 import json
 import os
 import platform
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
@@ -48,7 +51,8 @@ ARITHMETIC = {
     "fp16-pair": dict(products=3, sustained=1640.0, probe="tools/probe/f16x2_probe.hip", inst="v_mfma_f32_32x32x16_f16",
                       text="fp32 operands as fp16 pairs (hi + remainder scaled by 2^11: 22-23 significant bits), 3 cross products per fp32 "
                            "product on v_mfma_f32_32x32x16_f16 with fp32 accumulation; error against fp64 below that of the fp32 MFMA "
-                           "(tests/test_gpu_accuracy.py): achieved/peak count algorithmic fp32 FLOP, peak = fp16 dense peak / 3"),
+                           "(tests/test_gpu_accuracy.py); operands beyond +-65504 raise a flag and the call is repeated with three bf16 "
+                           "planes (tests/test_gpu_range.py): achieved/peak count algorithmic fp32 FLOP, peak = fp16 dense peak / 3"),
 }
 
 
@@ -62,33 +66,44 @@ def kernel_peak(label):
     return BF16_MFMA_PEAK_TFLOPS / ARITHMETIC[a]["products"] if a else FP32_MFMA_PEAK_TFLOPS
 
 
+# batch: per GPU (weak scaling) for the training workloads; global_batch: over all GPUs (strong scaling) for sampling
 WORKLOADS = {
-    "train": dict(name="configs[1]: second-iteration UNet (1,1,64,128), MNIST-shaped 1x28x28, batch 256 training step "
+    "train": dict(name="configs[1]: second-iteration UNet (1,1,64,128), MNIST-shaped 1x28x28, batch 256 per GPU training step "
                        "(noise, add_noise, fwd, eps-MSE, bwd, Adam)", variant=2, cin=1, hw=28, batch=256, labels=False,
                   metric="train samples/sec", unit="samples/s"),
-    "sample": dict(name="configs[2]: third-iteration UNet (1,1,64,128,num_classes=10), 1x32x32, full T=1000 ancestral sampling, "
-                        "batch 4096 sharded over 8 GPUs (512 per GPU)", variant=3, cin=1, hw=32, batch=512, labels=True,
+    "sample": dict(name="configs[2]: third-iteration UNet (1,1,64,128,num_classes=10), 1x32x32, full T=1000 ancestral sampling of a "
+                        "global batch of 4096 images sharded over the GPUs", variant=3, cin=1, hw=32, global_batch=4096, labels=True,
                    metric="sampled images/sec (full T-step loop)", unit="images/s"),
     # the remaining configs: parity-test shapes, measurable here on request (never the default line)
     "sample_c1": dict(name="configs[0]: first-iteration UNet (1,1,64,128), 1x28x28, batch 64, full T=1000 ancestral sampling with the "
-                           "linear schedule (the case the reference runs on the CPU)", variant=1, cin=1, hw=28, batch=64, labels=False,
+                           "linear schedule (the case the reference runs on the CPU)", variant=1, cin=1, hw=28, global_batch=64, labels=False,
                       metric="sampled images/sec (full T-step loop)", unit="images/s"),
     "train_color": dict(name="configs[3]: third-iteration UNet (3,3,64,128), colour 3x32x32, batch 256 per GPU training step, "
                              "data-parallel gradient all-reduce", variant=3, cin=3, hw=32, batch=256, labels=False,
                         metric="train samples/sec", unit="samples/s"),
     "sample_64": dict(name="configs[4]: third-iteration UNet (3,3,64,128), 3x64x64 (attention at N=4096, 1024, 256), full T=1000 "
-                           "ancestral sampling, batch 8192 sharded over 8 GPUs (1024 per GPU)", variant=3, cin=3, hw=64, batch=1024,
-                      labels=False, metric="sampled images/sec (full T-step loop)", unit="images/s"),
+                           "ancestral sampling of a global batch of 8192 images sharded over the GPUs (8 GPUs: 1024 each)", variant=3, cin=3,
+                      hw=64, global_batch=8192, labels=False, metric="sampled images/sec (full T-step loop)", unit="images/s"),
 }
 
 
-def build_model(variant, cin, labels):
+def build_model(variant, cin, labels, bounded_samples=False):
+    """Reference-default initialisation under a fixed seed with non-trivial BatchNorm statistics and attention gates.
+    bounded_samples: the output layer is scaled by 1/64. An UNTRAINED network's eps-hat has nothing to do with the noise
+    in x_t, and with the default output layer a 1000-step trajectory grows to 4e7 (a trained network keeps x_t at unit
+    scale); scaled, the trajectory stays within a few thousand, so that the whole call runs in the arithmetic a trained
+    network would run in. Same layers, same shapes, same kernels, same FLOP."""
+    import torch
     import diffusion_model_amd as pkg
     from seeding import seeded_state_dict
     U = pkg.make_unet_class(variant)
     torch.manual_seed(0)
     m = U(cin, cin, 64, 128, num_classes=10) if (variant == 3 and labels) else U(cin, cin, 64, 128)
-    m.load_state_dict(seeded_state_dict(m.state_dict(), 0))      # non-trivial BN statistics and attention gates
+    sd = seeded_state_dict(m.state_dict(), 0)
+    if bounded_samples:
+        sd["final_conv.weight"] = sd["final_conv.weight"] / 64.0
+        sd["final_conv.bias"] = sd["final_conv.bias"] / 64.0
+    m.load_state_dict(sd)
     return m
 
 
@@ -106,7 +121,8 @@ def log(msg, trace=False):
 def reverse_step_bandwidth(dev, loop_elements, big=1 << 26, iters=20):
     """The fused reverse-step kernel (x_{t-1} from x_t, eps-hat, z: 16 algorithmic bytes per element) against the HBM
     peak, timed with HIP events outside the timed steps: at 2^26 elements, where every operand comes from HBM, and at
-    the size one denoising step of this workload launches it with (small enough to stay in the caches)."""
+    the size one denoising step of this workload launches it with."""
+    import torch
     from diffusion_model_amd._lib import call
     res = {"kernel": "reverse_step", "bytes_per_element": 16, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
     for tag, n in (("hbm_resident", big), ("loop_size", loop_elements)):
@@ -164,65 +180,89 @@ def host_description():
     return model
 
 
-def cpu_baseline(workload, wl, batch, min_steps=3, seconds=8.0):
-    """The CPU oracle (a torch-CPU restatement of the reference) timed on the host cores at the workload's own batch:
-    at least `min_steps` steps and at least `seconds` seconds."""
+def cpu_baseline_one(workload, wl, batch, threads, min_steps=2, seconds=8.0):
+    """The CPU oracle (a torch-CPU restatement of the reference) timed on `threads` host cores on a bounded sample of
+    the workload: at least `min_steps` steps and about `seconds` seconds, at batch `batch` (the workload's own batch
+    when a step of it fits that budget, a smaller one otherwise: the rate per image hardly depends on it)."""
+    import torch
     from oracle import ddpm_oracle as O
-    m = build_model(wl["variant"], wl["cin"], wl["labels"])
-    sd = {k: v.clone() for k, v in m.state_dict().items()}
-    betas = O.schedule_betas("linear", T_FULL)
-    alphas, abar = O.schedule_tables(betas)
-    B, cin, hw = batch, wl["cin"], wl["hw"]
-    common = dict(cores=torch.get_num_threads(), kind="port", cpu=host_description(), torch=torch.__version__, batch=B)
-    n, t0 = 0, time.time()
-    if workload.startswith("sample"):
-        x = torch.randn(B, cin, hw, hw)
-        t = torch.full((B,), 500, dtype=torch.long)
-        y = torch.tensor([3]) if wl["labels"] else None
-        c = O.step_coefficients(betas, alphas, abar, 500)
-        with torch.no_grad():
-            while n < min_steps or time.time() - t0 < seconds:
-                eps = O.unet_forward(sd, wl["variant"], x, t, y, train=False)[0]
-                x = torch.from_numpy(O.reverse_step(x.numpy(), eps.numpy(), torch.randn_like(x).numpy(), *c))
-                n += 1
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        m = build_model(wl["variant"], wl["cin"], wl["labels"])
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        betas = O.schedule_betas("linear", T_FULL)
+        alphas, abar = O.schedule_tables(betas)
+        B, cin, hw = batch, wl["cin"], wl["hw"]
+        common = dict(cores=torch.get_num_threads(), kind="port", cpu=host_description(), torch=torch.__version__, batch=B)
+        n, t0 = 0, time.time()
+        if workload.startswith("sample"):
+            x = torch.randn(B, cin, hw, hw)
+            t = torch.full((B,), 500, dtype=torch.long)
+            y = torch.tensor([3]) if wl["labels"] else None
+            c = O.step_coefficients(betas, alphas, abar, 500)
+            with torch.no_grad():
+                while n < min_steps or time.time() - t0 < seconds:
+                    eps = O.unet_forward(sd, wl["variant"], x, t, y, train=False)[0]
+                    x = torch.from_numpy(O.reverse_step(x.numpy(), eps.numpy(), torch.randn_like(x).numpy(), *c))
+                    n += 1
+            dt = (time.time() - t0) / n
+            return dict(value=round(B / (T_FULL * dt), 5), unit="images/s", **common,
+                        sample=f"{n} denoising steps of the CPU oracle at batch {B} ({dt:.2f} s each), extrapolated to the {T_FULL}-step loop")
+        params = {k: v.clone() for k, v in sd.items() if O.is_param(k)}
+        state, cur = {}, dict(sd)
+        while n < min_steps or time.time() - t0 < seconds:
+            x0, noise = torch.rand(B, cin, hw, hw) * 2 - 1, torch.randn(B, cin, hw, hw)
+            t = torch.randint(0, T_FULL, (B,))
+            noisy = torch.from_numpy(O.add_noise(x0.numpy(), noise.numpy(), t.numpy(), abar))
+            cur.update(params)
+            _, grads, _, bufs = O.loss_and_grads(cur, wl["variant"], noisy, t, noise)
+            cur.update(bufs)
+            O.adam_step(params, grads, state)
+            n += 1
         dt = (time.time() - t0) / n
-        return dict(value=round(B / (T_FULL * dt), 5), unit="images/s", **common,
-                    sample=f"{n} denoising steps of the CPU oracle at batch {B} ({dt:.2f} s each), extrapolated to the {T_FULL}-step loop")
-    params = {k: v.clone() for k, v in sd.items() if O.is_param(k)}
-    state, cur = {}, dict(sd)
-    while n < min_steps or time.time() - t0 < seconds:
-        x0, noise = torch.rand(B, cin, hw, hw) * 2 - 1, torch.randn(B, cin, hw, hw)
-        t = torch.randint(0, T_FULL, (B,))
-        noisy = torch.from_numpy(O.add_noise(x0.numpy(), noise.numpy(), t.numpy(), abar))
-        cur.update(params)
-        _, grads, _, bufs = O.loss_and_grads(cur, wl["variant"], noisy, t, noise)
-        cur.update(bufs)
-        O.adam_step(params, grads, state)
-        n += 1
-    dt = (time.time() - t0) / n
-    return dict(value=round(B / dt, 3), unit="samples/s", **common,
-                sample=f"{n} training steps of the CPU oracle (torch-CPU autograd + Adam) at batch {B} ({dt:.2f} s each)")
+        return dict(value=round(B / dt, 3), unit="samples/s", **common,
+                    sample=f"{n} training steps of the CPU oracle (torch-CPU autograd + Adam) at batch {B} ({dt:.2f} s each)")
+    finally:
+        torch.set_num_threads(prev)
+
+
+def cpu_baseline(workload, wl, batch):
+    """The baseline on the threads torch uses by default on this host (the box's CPU share) and, for comparison with
+    other hosts, on 8 threads (under "threads_8")."""
+    import torch
+    b = min(batch, 256)            # a 4096-image step of the oracle would take minutes; the per-image rate is the same
+    full = cpu_baseline_one(workload, wl, b, torch.get_num_threads())
+    if torch.get_num_threads() != 8:
+        full["threads_8"] = {k: v for k, v in cpu_baseline_one(workload, wl, b, 8, seconds=6.0).items() if k in ("value", "unit", "cores", "sample")}
+    return full
 
 
 class Job:
     """One workload on this rank: model, the step function, and what the measurement collects."""
 
     def __init__(self, workload, args, ctx):
+        import torch
         import diffusion_model_amd as pkg
         from diffusion_model_amd import parallel
-        from diffusion_model_amd._lib import call
         from diffusion_model_amd.schedule import step_coefficients_host
         self.workload, self.args, self.ctx = workload, args, ctx
         self.wl = wl = WORKLOADS[workload]
-        dev, rank = ctx["dev"], ctx["rank"]
-        self.B = B = args.batch or wl["batch"]
+        dev, rank, world = ctx["dev"], ctx["rank"], ctx["world"]
+        self.sampling = workload.startswith("sample")
+        if self.sampling:
+            self.global_batch = args.batch * world if args.batch else wl["global_batch"]
+            lo, hi = parallel.shard_range(self.global_batch, world, rank)
+            self.B = B = hi - lo                       # this rank's shard of the global batch
+        else:
+            self.B = B = args.batch or wl["batch"]
+            self.global_batch = B * world
         self.shape = shape = (B, wl["cin"], wl["hw"], wl["hw"])
-        self.model = model = build_model(wl["variant"], wl["cin"], wl["labels"]).to(dev)
+        self.model = model = build_model(wl["variant"], wl["cin"], wl["labels"], bounded_samples=self.sampling).to(dev)
         betas = pkg.BetaScheduler(T_FULL, device=dev).get_schedule("linear")
         self.dm = dm = pkg.make_diffusion_class(wl["variant"])(model, betas, T_FULL)
         gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
         torch.manual_seed(4321 + rank)      # build_model seeds every rank alike (same weights); the noise of the steps must differ per rank
-        self.sampling = workload.startswith("sample")
         self.state = state = {}
         self.reducer = None
         if self.sampling:
@@ -275,6 +315,7 @@ class Job:
     def prepass(self):
         """Per-kernel HIP events for the multi-GPU case, taken BEFORE the process group exists (2 steps, no
         collective), so that event recording never interleaves with RCCL traffic in the timed region."""
+        import torch
         self.one_step()
         self.model._engine.prof = []
         self.one_step()
@@ -298,25 +339,27 @@ class Job:
         # Settling steps before the W warm-up steps: the first second of a process holds one-off host stalls
         # (first-use initialisation inside the HIP runtime and the caching allocator: a single step of the first
         # dozen takes 50-80 ms instead of 29), which would otherwise land inside a short timed region.
+        import torch
         args, multi = self.args, self.ctx["multi"]
         n = 0
         if multi:     # every rank must issue the same number of collectives: a fixed count instead of a time budget
-            for _ in range(int(round(args.settle * 30))):
+            for _ in range(max(2, int(round(args.settle * (8 if self.sampling else 30))))):
                 self.one_step()
                 n += 1
         else:
             t_end = time.perf_counter() + args.settle
-            while time.perf_counter() < t_end:
+            while time.perf_counter() < t_end or n < 2:
                 self.one_step()
                 n += 1
         torch.cuda.synchronize()
         return n
 
-    def timed(self, barrier):
+    def timed(self, barrier, profile=True):
+        import torch
         args, multi = self.args, self.ctx["multi"]
         for _ in range(args.warmup):
             self.one_step()
-        if not multi:
+        if not multi and profile:
             self.model._engine.prof = []
             self.model._engine.prof_stride = max(1, args.profile_stride)
         barrier()
@@ -326,7 +369,7 @@ class Job:
             log(f"rank {self.ctx['rank']}: step {i} issued", True)
         barrier()
         dt = time.perf_counter() - t0
-        if not multi:
+        if not multi and profile:
             self.prof = self.model._engine.prof
             self.model._engine.prof = None
         if self.sampling:
@@ -335,45 +378,73 @@ class Job:
             assert self.state["loss"] == self.state["loss"], "loss is NaN"
         return dt
 
-    def full_call(self, T=50):
-        """One real DiffusionModel.sample() call (its own T-step schedule, the ten stage copies to the host included),
-        wall clock: T denoising steps must cost T times the timed step."""
-        import diffusion_model_amd as pkg
+    def full_range_steps(self, barrier):
+        """The same K steps with three bf16 planes per operand (no range limit) instead of the fp16 pair."""
+        from diffusion_model_amd._lib import conv_math
+        eng = self.model._engine
+        if eng.effective_math() != "f16x2":
+            return None
+        before = eng.math
+        eng.math = "bf16x3"
+        try:
+            self.one_step()
+            self.one_step()                      # packs the weights in the other format, sizes the allocator's pools
+            dt = self.timed(barrier, profile=False)
+        finally:
+            eng.math = before
+            self.one_step()                      # back on the default arithmetic (packed weights of both modes stay cached)
+        return dt
+
+    def full_call(self, barrier, T=T_FULL):
+        """ONE real DiffusionModel.sample() call of this rank's shard over the full T-step schedule, wall clock between
+        two barriers, the ten stage copies to the host included: the quantity the metric names."""
+        import torch
         dev = self.ctx["dev"]
-        betas = pkg.BetaScheduler(T, device=dev).get_schedule("linear")
-        dm = pkg.make_diffusion_class(self.wl["variant"])(self.model, betas, T)
+        dm = self.dm
+        if T != T_FULL:
+            import diffusion_model_amd as pkg
+            dm = pkg.make_diffusion_class(self.wl["variant"])(self.model, pkg.BetaScheduler(T, device=dev).get_schedule("linear"), T)
         kw = dict(labels=self.labels) if self.wl["variant"] == 3 else {}
-        torch.cuda.synchronize()
+        if self.args.noise == "philox":
+            kw["in_kernel_noise"] = True
+        eng = self.model._engine
+        fallbacks0 = eng.range_fallbacks
+        barrier()
         t0 = time.perf_counter()
         with torch.no_grad():
             stages = dm.sample(self.shape, dev, **kw)
+        barrier()
         dt = time.perf_counter() - t0
         assert len(stages) == 10 and stages[-1][1] == 0 and torch.isfinite(stages[-1][0]).all()
-        res = dict(T=T, seconds=round(dt, 4), ms_per_step=round(dt / T * 1e3, 3), stages=len(stages),
-                   what="DiffusionModel.sample(x_shape, device, labels) of a T=50 linear schedule at this batch, wall clock "
-                        "including the ten stage copies to pinned host memory")
-        if self.wl["cin"] == 1 and self.wl["hw"] == 32:
+        res = dict(T=T, seconds=round(dt, 4), ms_per_step=round(dt / T * 1e3, 3), stages=len(stages), shard=list(self.shape),
+                   range_fallbacks=eng.range_fallbacks - fallbacks0, arithmetic_at_the_end=eng.effective_math(),
+                   largest_sample_magnitude=round(float(stages[-1][0].abs().max()), 1),
+                   what=f"DiffusionModel.sample(x_shape, device{', labels' if kw.get('labels') is not None else ''}) over the full "
+                        f"T = {T} linear schedule on every rank's shard, wall clock between two barriers, including the ten stage "
+                        "copies to pinned host memory")
+        if self.wl["cin"] == 1 and self.wl["hw"] == 32 and self.ctx["rank"] == 0:
             # the "+classifier.py path" of this configuration: score the samples with the MNIST classifier (random weights
             # here: the trained ones are not part of the synthetic workload) and reduce to the Inception-Score terms
+            import diffusion_model_amd as pkg
             from diffusion_model_amd import scorer
             torch.manual_seed(1)
             clf = pkg.SimpleCNN().to(dev).eval()
-            imgs = stages[-1][0]
+            imgs = ((stages[-1][0] + 1) / 2).clamp(0, 1)   # the callers' post-processing (first-iteration/generate_samples.py:36-37)
             scorer.inception_score(imgs, clf)              # first call packs the weights
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             mean, _ = scorer.inception_score(imgs, clf)
             res["score"] = dict(seconds=round(time.perf_counter() - t0, 5), images=int(imgs.shape[0]), inception_score=round(float(mean), 4),
-                                what="SimpleCNN logits + softmax + 10-split Inception-Score reduction of the final samples (host "
+                                what="SimpleCNN logits + softmax + 10-split Inception-Score reduction of rank 0's final samples (host "
                                      "images in, scalar out), HIP kernels")
-        return res
+        return res, dt
 
     # ---- report -------------------------------------------------------------------------------
     def report(self, dt):
         args, ctx, wl = self.args, self.ctx, self.wl
         world, multi = ctx["world"], ctx["multi"]
         sec_per_step = dt / args.steps
-        total_b = self.B * world
+        total_b = self.global_batch
         value = total_b / (T_FULL * sec_per_step) if self.sampling else total_b / sec_per_step
         agg = {}
         for label, flops, e0, e1 in self.prof:
@@ -398,12 +469,14 @@ class Job:
         kernels = {k: dict(sampled_launches=v[2], avg_ms=round(v[1] / v[2] * 1e3, 4), tflops=round(v[0] / v[1] / 1e12, 2),
                            peak_tflops=round(kernel_peak(k), 1), frac=round(v[0] / v[1] / 1e12 / kernel_peak(k), 4),
                            share_of_step=round(v[1] / prof_steps / sec_per_step, 3)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
-        from diffusion_model_amd._lib import conv_math
-        cfg = {"workload": wl["name"], "per_gpu_batch": self.B, "global_batch": total_b, "conv_math": conv_math()}
+        cfg = {"workload": wl["name"], "per_gpu_batch": self.B, "global_batch": total_b, "conv_math": self.model._engine.effective_math(),
+               "weights": "reference-default initialisation under torch.manual_seed(0), BatchNorm running statistics and attention gates "
+                          "randomised (tests/golden/seeding.py)"}
         if self.sampling:
+            cfg["weights"] += ("; output layer scaled by 1/64 so that this untrained network's 1000-step trajectory stays within a few "
+                               "thousand, as a trained network's does, instead of growing to 4e7")
             cfg.update(T=T_FULL, step="one denoising step as DiffusionModel.sample() runs it: noise draw (%s) + UNet eval forward whose final "
-                                      "1x1 conv is fused with the reverse-step update; images/s = global_batch / (T * seconds_per_step)"
-                                      % ("in-kernel Philox" if args.noise == "philox" else "torch.randn_like"))
+                                      "1x1 conv is fused with the reverse-step update" % ("in-kernel Philox" if args.noise == "philox" else "torch.randn_like"))
         else:
             bn = "global batch statistics (all-reduce of per-rank sums, forward and backward)" if (multi and args.batchnorm == "sync") \
                 else "per-rank batch statistics"
@@ -422,7 +495,7 @@ class Job:
             if arithmetic_of(dom[0]) else None
         kind = "sample" if self.workload == "sample" else "train"
         tfile = next((f for f in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic_{kind}.txt") for r in (3, 2, 1)) if os.path.exists(f)), None)
-        if kernel_symbol and self.workload in ("train", "sample") and tfile:
+        if kernel_symbol and self.workload in ("train", "sample") and tfile and (not self.sampling or self.B == 512 or "r03" in tfile):
             for line in open(tfile):
                 f = line.split()
                 if len(f) > 4 and kernel_symbol in line and f[0].isdigit():
@@ -436,7 +509,7 @@ class Job:
         return {
             "metric": wl["metric"], "value": round(value, 4), "unit": wl["unit"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if self.sampling else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": cfg,
             "roofline": {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": round(kernel_peak(dom[0]), 1),
                          "unit": "TFLOP/s", "frac": round(achieved / kernel_peak(dom[0]), 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -453,6 +526,26 @@ class Job:
         }
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run on
+    127.0.0.1) before this process has touched a GPU, pass rank 0's JSON line through, leave with their exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"no launcher in the environment: starting {args.gpus} ranks: {' '.join(cmd)}")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    sys.exit(proc.returncode if proc.returncode or lines else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -460,8 +553,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="both", choices=["both"] + list(WORKLOADS),
                     help="both (default) = train (the line's top level) + sample (its \"sampling\" object)")
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's; sampling: its global batch / N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-call", action="store_true", help="sampling: skip the real T=1000 sample() call (value = the K-step figure)")
+    ap.add_argument("--no-full-range", action="store_true", help="skip the K steps in the three-plane bf16 arithmetic")
+    ap.add_argument("--full-T", type=int, default=T_FULL, help="timesteps of the real sample() call (a shorter schedule for quick runs)")
     ap.add_argument("--optimizer", default="hip", choices=["hip", "torch"], help="training: diffusion_model_amd.optim.Adam or torch.optim.Adam")
     ap.add_argument("--profile-stride", type=int, default=7,
                     help="bracket every N-th MFMA launch of the timed steps with HIP events (1 = all; events cost GPU time)")
@@ -469,8 +565,8 @@ def main():
     ap.add_argument("--allreduce", default="bucketed", choices=["bucketed", "flat"],
                     help="data-parallel training: gradient buckets all-reduced while the backward runs, or one flat all-reduce after it")
     ap.add_argument("--bucket-mb", type=int, default=8, help="gradient bucket size in MiB (bucketed all-reduce)")
-    ap.add_argument("--batchnorm", default="local", choices=["local", "sync"],
-                    help="data-parallel training: per-rank batch statistics, or global ones (the reference's semantics at the global batch)")
+    ap.add_argument("--batchnorm", default="sync", choices=["local", "sync"],
+                    help="data-parallel training: global batch statistics (the reference's semantics at the global batch; default), or per-rank ones")
     ap.add_argument("--noise", default="torch", choices=["torch", "philox"],
                     help="sampling: per-step noise from torch.randn_like (sample()'s default) or drawn inside the fused last kernel")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -479,17 +575,20 @@ def main():
                                                               "even with one rank")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args)               # does not return
+
+    import torch
+
     # stdout carries exactly one JSON line: native libraries that print there (RCCL's version banner at communicator
     # creation, gloo's connection notes) are sent to stderr by pointing fd 1 at fd 2; the line goes to the saved fd
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        sys.exit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`")
     if args.same_device:
         local = 0
     torch.cuda.set_device(local)
@@ -505,7 +604,6 @@ def main():
     names = ["train", "sample"] if args.workload == "both" else [args.workload]
     if args.workload == "both" and args.batch:
         sys.exit("--batch needs a single --workload")
-    jobs = [Job(n, args, ctx) for n in names]
 
     def barrier():
         torch.cuda.synchronize()
@@ -519,55 +617,78 @@ def main():
             torch.cuda.synchronize()
             log(f"rank {rank}: left barrier", True)
 
-    if multi:
-        log("multi-GPU: profiling pre-pass (no collectives)")
-        for j in jobs:
-            j.prepass()
-        import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        if os.environ.get("DDPM_BENCH_NO_PG"):      # diagnostic: the multi-GPU control flow without a process group
-            dist_mod = None
-        elif args.backend == "nccl":
-            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist_mod.init_process_group(args.backend, rank=rank, world_size=world)
-        ctx["dist"] = dist_mod
-        for j in jobs:
-            j.attach_distributed()
+    def max_over_ranks(dt):
+        if ctx["dist"] is None:
+            return dt
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        parallel.all_reduce_(tt, op=ctx["dist"].ReduceOp.MAX)
+        return tt.item()
 
     results = []
-    for j in jobs:
-        log(f"{j.workload}: settling")
+    for name in names:
+        # one workload at a time: the sampling half's 4096-image activations and the training half's tape never coexist
+        j = Job(name, args, ctx)
+        if multi:
+            log(f"{name}: multi-GPU profiling pre-pass (no collectives)")
+            j.prepass()
+            if ctx["dist"] is None:
+                import torch.distributed as dist_mod
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29533")
+                if os.environ.get("DDPM_BENCH_NO_PG"):      # diagnostic: the multi-GPU control flow without a process group
+                    dist_mod = None
+                elif args.backend == "nccl":
+                    dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                else:
+                    dist_mod.init_process_group(args.backend, rank=rank, world_size=world)
+                ctx["dist"] = dist_mod
+            j.attach_distributed()
+        log(f"{name}: settling")
         n = j.settle()
-        log(f"{j.workload}: {n} settling steps; warm-up and timed steps")
-        dt = j.timed(barrier)
-        log(f"{j.workload}: {dt / args.steps * 1e3:.2f} ms/step on this rank")
-        if ctx["dist"] is not None:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            parallel.all_reduce_(tt, op=ctx["dist"].ReduceOp.MAX)
-            dt = tt.item()
+        log(f"{name}: {n} settling steps; warm-up and timed steps")
+        dt = max_over_ranks(j.timed(barrier))
+        log(f"{name}: {dt / args.steps * 1e3:.2f} ms/step")
         res = j.report(dt)
-        if rank == 0 and not multi:
-            if j.sampling:
+        if not args.no_full_range:
+            fr = j.full_range_steps(barrier)
+            if fr is not None:
+                fr = max_over_ranks(fr)
+                per = fr / args.steps
+                res["full_range"] = dict(conv_math="bf16x3", ms_per_step=round(per * 1e3, 3),
+                                         value=round(j.global_batch / (T_FULL * per) if j.sampling else j.global_batch / per, 4), unit=j.wl["unit"],
+                                         what="the same K steps with every operand as three bf16 planes (six cross products, no range limit): "
+                                              "the arithmetic a call falls back to when an operand leaves fp16's range")
+                log(f"{name}: {per * 1e3:.2f} ms/step in the full-range arithmetic")
+        if j.sampling:
+            res["per_step"] = dict(value=res["value"], unit=res["unit"], ms_per_step=res["ms_per_step"], steps=args.steps,
+                                   what="global_batch / (1000 * seconds per timed denoising step): the K-step figure")
+            if not args.no_full_call:
+                log(f"{name}: one real sample() call of T = {args.full_T} at {j.shape}")
+                call_res, wall = j.full_call(barrier, args.full_T)
+                wall = max_over_ranks(wall)
+                call_res["seconds"] = round(wall, 4)
+                call_res["timed_step_ms"] = res["ms_per_step"]
+                res["full_call"] = call_res
+                if args.full_T == T_FULL:
+                    res["value"] = round(j.global_batch / wall, 4)     # the metric itself: images per second of the whole T-step call
+                    res["value_source"] = "full_call: global_batch / wall seconds of one DiffusionModel.sample() over T = 1000"
+                log(f"{name}: sample() took {wall:.2f} s = {j.global_batch / wall:.2f} images/s")
+            if rank == 0 and not multi:
                 res["hbm_kernel"] = reverse_step_bandwidth(dev, j.B * j.wl["cin"] * j.wl["hw"] * j.wl["hw"])
-                res["full_call"] = j.full_call()
-                res["full_call"]["timed_step_ms"] = res["ms_per_step"]
-        results.append((j, res))
-        if len(jobs) > 1:          # free the first workload's model and activations before the next one runs
-            j.model, j.dm, j.one_step, j.state = None, None, None, {}
-            torch.cuda.empty_cache()
+        results.append((j.workload, j.wl, j.B, res))
+        del j
+        torch.cuda.empty_cache()
 
     if rank == 0:
-        out = results[0][1]
+        out = results[0][3]
         if not multi and not args.no_cpu_baseline:
-            for j, res in results:
-                log(f"{j.workload}: CPU baseline")
-                res["cpu_baseline"] = cpu_baseline(j.workload, j.wl, j.B)
+            for workload, wl, B, res in results:
+                log(f"{workload}: CPU baseline")
+                res["cpu_baseline"] = cpu_baseline(workload, wl, B)
         if len(results) > 1:
-            samp = results[1][1]
-            out["sampling"] = {k: samp[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "kernels", "hbm_kernel",
-                                                    "full_call", "cpu_baseline") if k in samp}
+            samp = results[1][3]
+            out["sampling"] = {k: samp[k] for k in ("metric", "value", "value_source", "unit", "scaling", "ms_per_step", "config", "per_step", "full_call",
+                                                    "full_range", "roofline", "kernels", "hbm_kernel", "cpu_baseline") if k in samp}
             out.setdefault("hbm_kernel", samp.get("hbm_kernel"))
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if ctx["dist"] is not None:

@@ -96,6 +96,8 @@ _SIGNATURES = {
     "ddpm_grad_scale": [P, I64, P, P, P],
     "ddpm_scale_tensors": [I32, P, P, P, P],
     "ddpm_conv_math": [],
+    "ddpm_set_conv_math": [I32],
+    "ddpm_range_flag_read": [P, I32, P],
 }
 
 _lib = None
@@ -137,9 +139,39 @@ def packed_floats(taps, rows, cin):
     return int(lib().ddpm_packed_weight_floats(taps, rows, cin))
 
 
+MATH_MODES = ("fp32", "bf16x3", "f16x2")
+
+
 def conv_math():
-    """Arithmetic of the MFMA-fed convolutions in this process: 'fp32', 'bf16x3' or 'f16x2' (DDPM_CONV_MATH)."""
-    return ("fp32", "bf16x3", "f16x2")[int(lib().ddpm_conv_math())]
+    """Arithmetic of the MFMA-fed kernels that the library is in right now: 'fp32', 'bf16x3' or 'f16x2' (it starts
+    in the one DDPM_CONV_MATH names; set_conv_math / math_scope change it)."""
+    return MATH_MODES[int(lib().ddpm_conv_math())]
+
+
+def set_conv_math(mode):
+    """Switch the library's arithmetic; returns the previous mode. Packed weights belong to the mode they were
+    packed in: callers key their caches on conv_math()."""
+    prev = conv_math()
+    if mode != prev:
+        call("ddpm_set_conv_math", MATH_MODES.index(mode))
+    return prev
+
+
+class math_scope:
+    """`with math_scope('bf16x3'):` runs the body in that arithmetic and restores the previous one (None = no change)."""
+
+    def __init__(self, mode):
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        if self.mode is not None:
+            self.prev = set_conv_math(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            set_conv_math(self.prev)
+        return False
 
 
 def call(name, *args):

@@ -41,6 +41,7 @@ struct AttnParams {
     float* attn_raw;    // optional [B][N][C]
     float* lse;         // optional [B][N]
     int n, c, dqp, lq, ldx, ldo;
+    unsigned* range_flag;   // fp16-pair kernels: raised when q, k or v lies beyond fp16's range
 };
 
 template <int DQ, int NCT>
@@ -263,8 +264,17 @@ __device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4
     lo = u32x4{l[0], l[1], l[2], l[3]};
 }
 
-__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, int plane_stride) {
+// (the same with the range watch of conv_common.h: for q, k and v, which come from memory; probabilities need none)
+__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, float& amax) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[2 * e], v[2 * e + 1]});
+    split8_f16(v, hi, lo);
+}
+
+__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, int plane_stride, float& amax) {
     unsigned h0, l0, h1, l1;
+    ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[0], v[1]});
+    ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[2], v[3]});
     ddpm::conv::split2_pair(ddpm::conv::f32x2{v[0], v[1]}, h0, l0);
     ddpm::conv::split2_pair(ddpm::conv::f32x2{v[2], v[3]}, h1, l1);
     *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
@@ -291,6 +301,7 @@ using ddpm::conv::mfma16;
 template <int DQ, int QB, int NCT, bool F16>
 __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnParams p) {
     if constexpr (F16) ddpm::conv::fp16_saturate();
+    float amax = 0.f;                           // F16: largest magnitude of q, k, v this thread has turned into an fp16 pair
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     constexpr int NPL = F16 ? 2 : 3;            // operand planes
     constexpr int CS = 32 * NCT;
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
                     v[4 + j] = x1[j];
                 }
             }
-            if constexpr (F16) split8_f16(v, qf[qb][kc][0], qf[qb][kc][1]);
+            if constexpr (F16) split8_f16(v, qf[qb][kc][0], qf[qb][kc][1], amax);
             else split8(v, qf[qb][kc][0], qf[qb][kc][1], qf[qb][kc][NPL - 1]);
         }
     }
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
             const int f = tid + 256 * i;
             const int row = f / (DQ / 4), c4 = f % (DQ / 4);
             if (f < KF4) {
-                if constexpr (F16) split4_store_f16(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL);
+                if constexpr (F16) split4_store_f16(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL, amax);
                 else split4_store(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL);
             }
         }
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
         for (int i = 0; i < VPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CS / 4), c4 = f % (CS / 4);
-            if constexpr (F16) split4_store_f16(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE);
+            if constexpr (F16) split4_store_f16(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE, amax);
             else split4_store(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE);
         }
     };
@@ -555,6 +566,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
         __syncthreads();
     }
 
+    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, amax);
     if (!wave_active) return;
     if constexpr (F16) {
 #pragma unroll
@@ -604,6 +616,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
 template <int DQ, int NCT, int NW, bool F16>
 __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const AttnParams p) {
     if constexpr (F16) ddpm::conv::fp16_saturate();
+    float amax = 0.f;                   // F16: largest magnitude of q, k, v this thread has turned into an fp16 pair
     const dim3 bid = ddpm::xcd_block();
     constexpr int NPL = F16 ? 2 : 3;    // operand planes
     constexpr int NPR = F16 ? 3 : 6;    // MFMAs per fragment pair
@@ -652,7 +665,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
                     v[4 + j] = x1[j];
                 }
             }
-            if constexpr (F16) split8_f16(v, qf[kc][0], qf[kc][1]);
+            if constexpr (F16) split8_f16(v, qf[kc][0], qf[kc][1], amax);
             else split8(v, qf[kc][0], qf[kc][1], qf[kc][NPL - 1]);
         }
     }
@@ -692,14 +705,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
         const int f = tid + NT * i;
         const int row = f / (DQ / 4), c4 = f % (DQ / 4);
         if (f < KF4) {
-            if constexpr (F16) split4_store_f16(kreg[i], dst + row * KROW + c4 * 8, KPL);
+            if constexpr (F16) split4_store_f16(kreg[i], dst + row * KROW + c4 * 8, KPL, amax);
             else split4_store(kreg[i], dst + row * KROW + c4 * 8, KPL);
         }
     };
     auto store_v1 = [&](int i, unsigned char* dst) {
         const int f = tid + NT * i;
         const int row = f / (CS / 4), c4 = f % (CS / 4);
-        if constexpr (F16) split4_store_f16(vreg[i], dst + row * VROW + c4 * 8, VPLANE);
+        if constexpr (F16) split4_store_f16(vreg[i], dst + row * VROW + c4 * 8, VPLANE, amax);
         else split4_store(vreg[i], dst + row * VROW + c4 * 8, VPLANE);
     };
 
@@ -925,6 +938,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
     }
     body(std::false_type{}, tiles - 1);
 
+    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, amax);
     if (!wave_active) return;
     if constexpr (F16) {
 #pragma unroll
@@ -1096,6 +1110,8 @@ extern "C" int ddpm_attention_fwd(const float* qkv, const float* x, int ldx, con
     p.lq = 2 * dq + c;
     p.ldx = ldx;
     p.ldo = ldo;
+    p.range_flag = ddpm::f16_math() ? ddpm::range_flag() : nullptr;
+    if (ddpm::f16_math() && !p.range_flag) return DDPM_E_LAUNCH;
     hipStream_t s = ddpm::as_stream(stream);
     if (ddpm::small_attention() && ddpm::attention_small_fwd_fits(n, c, dq))
         return ddpm::attention_small_fwd(qkv, x, ldx, gamma, temb, out, ldo, attn_raw, lse, batch, n, c, dq, s);

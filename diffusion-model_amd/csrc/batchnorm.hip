@@ -457,14 +457,25 @@ namespace {
 double* g_scratch_ptr[kMaxDevices];      // device address of `scratch` on each GPU (null until first use there)
 std::mutex g_scratch_mutex;
 
-// Device address of this GPU's copy of `scratch`, looked up on the first call on that device.
-int scratch_for_current_device(double** out) {
+// Device address of this GPU's copy of `scratch`, looked up on the first call on that device. The kernels run on
+// `stream`: a stream that belongs to another GPU than the current one would hand that GPU's kernels THIS GPU's
+// address, so such a call is refused.
+int scratch_for_current_device(double** out, hipStream_t stream) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
         ddpm::set_error("ddpm_bn_stats_noalloc: cannot identify the current device (%s, device %d, at most %d supported)",
                         hipGetErrorString(e), dev, kMaxDevices);
         return DDPM_E_LAUNCH;
+    }
+    if (stream != nullptr) {
+        hipDevice_t sdev = -1;
+        e = hipStreamGetDevice(stream, &sdev);
+        if (e != hipSuccess || static_cast<int>(sdev) != dev) {
+            ddpm::set_error("ddpm_bn_stats_noalloc: the stream belongs to device %d, the current device is %d (%s): make the stream's "
+                            "device current before the call", static_cast<int>(sdev), dev, hipGetErrorString(e));
+            return DDPM_E_INVALID;
+        }
     }
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
@@ -494,7 +505,7 @@ extern "C" int ddpm_bn_stats_noalloc(const float* x, int ldx, int64_t rows, int 
     DDPM_REQUIRE((ldx & 3) == 0 && ldx >= c && ddpm::aligned16(x) && ddpm::aligned16(mean) && ddpm::aligned16(invstd));
     DDPM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
     double* ws = nullptr;
-    if (int rc = scratch_for_current_device(&ws)) return rc;
+    if (int rc = scratch_for_current_device(&ws, as_stream(stream))) return rc;
     // every partial slot that the finishing kernel reads is written by the first kernel of this call
     // (nb blocks x 2 x c), so nothing left over from an earlier, larger call is ever read: no clearing needed
     const int nb = partial_blocks(rows, c);

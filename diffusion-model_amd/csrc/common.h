@@ -47,25 +47,24 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 constexpr int kMaxGridX = 1 << 20;
 
-// Arithmetic of the MFMA-fed convolutions, chosen once per process by DDPM_CONV_MATH in the environment:
+// Arithmetic of the MFMA-fed convolutions. The process starts in the mode DDPM_CONV_MATH names in the environment and
+// ddpm_set_conv_math() changes it at run time (the host mirror does so to repeat a call whose operands left fp16's range):
 //   "f16x2"  every fp32 operand as a pair of fp16 numbers (hi, and the remainder scaled by 2^11), three cross products
 //            per fp32 product on v_mfma_f32_32x32x16_f16 (the default);
 //   "bf16x3" every fp32 operand as the exact sum of three bf16 numbers, six cross products on
 //            v_mfma_f32_32x32x16_bf16;
 //   "fp32"   the plain fp32 MFMA kernels and the fp32 packed-weight format: a diagnostic switch for A/B measurements.
-// The packed-weight format follows the mode, so it holds for every kernel that reads packed weights.
+// The packed-weight format follows the mode, so packed weights must be used in the mode they were packed in.
 enum ConvMath { kMathFp32 = 0, kMathBf16x3 = 1, kMathF16x2 = 2 };
-inline int conv_math() {
-    static const int mode = [] {
-        const char* e = getenv("DDPM_CONV_MATH");
-        if (e && strcmp(e, "fp32") == 0) return static_cast<int>(kMathFp32);
-        if (e && strcmp(e, "bf16x3") == 0) return static_cast<int>(kMathBf16x3);
-        return static_cast<int>(kMathF16x2);
-    }();
-    return mode;
-}
+int conv_math();                       // runtime.hip
 inline bool split_math() { return conv_math() != kMathFp32; }
 inline bool f16_math() { return conv_math() == kMathF16x2; }
+
+// Device address, on the current GPU, of the word that the fp16-pair kernels set to 1 when an operand lies beyond
+// +-65504 (the pair representation clips there); null (with the error message set) when it cannot be looked up.
+// ddpm_range_flag_read() hands it to the host.
+unsigned* range_flag();                // runtime.hip
+constexpr float kF16Max = 65504.0f;
 
 // DDPM_ATTN_SMALL=0 (read once) routes feature maps of at most 64 pixels through the tiled attention
 // kernels instead of the one-workgroup-per-sample ones: a diagnostic switch for A/B measurements.

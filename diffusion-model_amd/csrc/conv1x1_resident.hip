@@ -90,6 +90,7 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
     const int g_begin = __builtin_amdgcn_readfirstlane(blockIdx.x * p.gpb);
     const int g_end = __builtin_amdgcn_readfirstlane(min(p.groups_total, g_begin + p.gpb));
     if (g_begin + wr >= g_end) return;
+    float amax = 0.f;   // F16: largest magnitude this thread has turned into an fp16 pair
 
     const int kc16 = p.kc16;
     const int ntile = (g_end - g_begin - wr + 3) >> 2;        // row groups g_begin + wr, + 4, ...
@@ -150,7 +151,7 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
 
     auto step = [&](f32x4 (&raw)[2], u32x4 (&b0cur)[NBW], u32x4 (&b0next)[NBW]) {
         u32x4 a0, a1, a2;
-        if constexpr (F16) split8_f16(raw[0], raw[1], a0, a1);
+        if constexpr (F16) split8_f16(raw[0], raw[1], a0, a1, amax);
         else split8(raw[0], raw[1], a0, a1, a2);
         kc = __builtin_amdgcn_readfirstlane(kc);
         t = __builtin_amdgcn_readfirstlane(t);
@@ -262,6 +263,7 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
     if (s < nsteps) step(ra[0], bw0[0], bw0[1]);
     if (s + 1 < nsteps) step(ra[1], bw0[1], bw0[0]);
     if (s + 2 < nsteps) step(ra[2], bw0[0], bw0[1]);
+    if constexpr (F16) raise_range_flag(p.range_flag, amax);
 }
 
 template <int NB0, int NB1, bool F16>
@@ -278,6 +280,7 @@ int launch_one_math(const GemmParams& p, int grid, int lds, hipStream_t s) {
 
 template <int NB0, int NB1>
 int launch_one(const GemmParams& p, int grid, int lds, hipStream_t s) {
+    if (f16_math() && !p.range_flag) return DDPM_E_LAUNCH;
     return f16_math() ? launch_one_math<NB0, NB1, true>(p, grid, lds, s) : launch_one_math<NB0, NB1, false>(p, grid, lds, s);
 }
 
@@ -369,11 +372,12 @@ __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned cha
         zero(acc[j]);
         zero(master[j]);
     }
+    float amax = 0.f;   // F16: largest magnitude this thread has turned into an fp16 pair
 
     // step c (0..3) of the current slab
     auto step = [&](int c, f32x4 (&raw)[2], u32x4 (&b0cur)[NBW], u32x4 (&b0next)[NBW]) {
         u32x4 a0, a1, a2;
-        if constexpr (F16) split8_f16(raw[0], raw[1], a0, a1);
+        if constexpr (F16) split8_f16(raw[0], raw[1], a0, a1, amax);
         else split8(raw[0], raw[1], a0, a1, a2);
         load_a(raw);
         auto term = [&](f32x16 (&cc)[NBW], const u32x4& a, int pb) {
@@ -486,6 +490,7 @@ __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned cha
             ++t;
         }
     }
+    if constexpr (F16) raise_range_flag(p.range_flag, amax);
 }
 
 template <int NB0, int NB1, bool F16>
@@ -529,13 +534,13 @@ int launch_slab_math(const GemmParams& p, int grid, int lds, hipStream_t s) {
 
 template <int NB0, int NB1>
 int launch_slab(const GemmParams& p, int grid, int lds, hipStream_t s) {
+    if (f16_math() && !p.range_flag) return DDPM_E_LAUNCH;
     return f16_math() ? launch_slab_math<NB0, NB1, true>(p, grid, lds, s) : launch_slab_math<NB0, NB1, false>(p, grid, lds, s);
 }
 
 // Returns 1 when the shape is not this kernel's (the caller goes on to the generic one).
 int launch_conv1x1_slab(GemmParams& p, hipStream_t s) {
     if (p.c2 > 0 || p.temb || p.m_total < 16384 || (p.ctot % (XK * kSlabChunks)) != 0) return 1;
-    if (static_cast<long long>(p.m_total) * p.ld1 * 4ll >= 0x7fffffffll) return 1;
     p.kc16 = p.ctot / XK;
     p.nbp = (p.n_total + 31) / 32;
     const long long wb = 3072ll * p.nbp * p.kc16;
@@ -562,6 +567,8 @@ int launch_conv1x1_slab(GemmParams& p, hipStream_t s) {
     if (best_nt == 0) return 1;
     p.n_tiles = best_nt;
     p.gpb = gpb;
+    // 32-bit offsets inside a workgroup's descriptors, which begin at ITS first row: its run of rows must stay below 2 GiB
+    if (static_cast<long long>(gpb) * 32 * (p.ld1 > p.ldo ? p.ld1 : p.ldo) * 4ll >= 0x7fffffffll) return 1;
     const int grid = ((p.groups_total + gpb - 1) / gpb) * p.n_tiles;
     const int lds = 2 * kSlabChunks * nbt * 3072;
     switch (nbt) {
@@ -583,11 +590,13 @@ int launch_conv1x1_resident(GemmParams& p, hipStream_t s) {
     p.nbp = (p.n_total + 31) / 32;
     const long long wb = 3072ll * p.nbp * p.kc16;
     if (p.nbp > 6 || wb > kMaxWeightLds) return launch_conv1x1_slab(p, s);
-    if (static_cast<long long>(p.m_total) * p.ld1 * 4ll >= 0x7fffffffll) return 1;   // 32-bit offsets inside one descriptor
     p.w_bytes = static_cast<unsigned>(wb);
     p.groups_total = (p.m_total + 31) / 32;
     const int gpb = (p.groups_total + 255) / 256;      // one workgroup per CU; its four row waves take every fourth group
     p.gpb = gpb;
+    // 32-bit offsets inside a workgroup's descriptors, which begin at ITS first row: its run of rows must stay below 2 GiB
+    // (the tensor itself may be larger)
+    if (static_cast<long long>(gpb) * 32 * (p.ld1 > p.ldo ? p.ld1 : p.ldo) * 4ll >= 0x7fffffffll) return 1;
     const int grid = (p.groups_total + gpb - 1) / gpb;
     const int lds = static_cast<int>(wb);
     switch (p.nbp) {

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     __shared__ __attribute__((aligned(16))) int rowb[256];   // sample index of every tile row, -1 = no such pixel
     if constexpr (F16) fp16_saturate();
+    float amax = 0.f;                           // F16: largest magnitude this thread has turned into an fp16 pair
     constexpr int XR = F16 ? XROW_F16 : XROW;   // LDS bytes per tile row
     constexpr int NPL = F16 ? 2 : 3;            // operand planes
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
         auto store_pass = [&](const f32x4 v, int k, unsigned char* buf) {
             const int L = srow + kPassRows * k;
             if (L < p.hrows) {
-                if constexpr (F16) split_store_f16(v, buf + L * XR + lq * 8);
+                if constexpr (F16) split_store_f16(v, buf + L * XR + lq * 8, amax);
                 else split_store(v, buf + L * XR + lq * 8);
             }
         };
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
             }
         }
     }
+    if constexpr (F16) raise_range_flag(p.range_flag, amax);
     if constexpr (STATS) {
         // the two lane halves hold different rows of the same column; so do the two waves with the same wn
         stat_sum += __shfl_xor(stat_sum, 32);
@@ -426,6 +428,7 @@ int launch_conv3x3_halo(GemmParams& p, hipStream_t s) {
     if (p.stat_partial && p.c2 > 0) return 1;   // statistics in the epilogue: single-source layers only
     // two workgroups per CU: 2 buffers of hrows rows each and the zero region within half of the LDS
     const bool f16 = f16_math();
+    if (f16 && !p.range_flag) return DDPM_E_LAUNCH;
     const int xr = f16 ? XROW_F16 : XROW;
     const int max_rows = min(NPASS * kPassRows, (160 * 1024 / 2 - 1024 - 256 - 384 - 512) / (2 * xr));
     int tg = 0;

@@ -45,6 +45,7 @@ struct GemmParams {
     int kc16;                            // 16-channel chunks per tap (split-bf16 path)
     int nbp;                             // 32-row blocks of the packed weights (split-bf16 path)
     int tile_groups, hrows;              // halo kernel: row groups per tile, LDS rows per buffer
+    unsigned* range_flag;                // fp16-pair kernels: raised when an operand lies beyond fp16's range
     double* stat_partial;                // halo kernel, optional: per-channel partial sums of the values written, [block][sum | sum of squares][cout]
     int stat_blocks;                     // set by the launcher: number of blocks in stat_partial
 };
@@ -150,9 +151,22 @@ static __device__ __forceinline__ void split2_pair(const f32x2 v, unsigned& hi, 
     lo = __builtin_bit_cast(unsigned, l);
 }
 
+// Range watch of the fp16-pair kernels: every thread keeps the largest magnitude it has turned into a pair (one
+// three-operand maximum per two elements) and, when it leaves, raises the library's range flag if that magnitude is
+// beyond fp16's largest finite value, i.e. if one of ITS operands was clipped. NaNs do not raise it (they are not
+// clipped either: they pass through the matrix instructions as they would in fp32).
+static __device__ __forceinline__ void watch2(float& amax, const f32x2 v) {
+    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])));
+}
+static __device__ __forceinline__ void raise_range_flag(unsigned* flag, float amax) {
+    if (amax > 65504.0f) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // four consecutive channels of one tile row -> the two fp16 planes of that row (8 bytes each, 32 bytes apart)
-static __device__ __forceinline__ void split_store_f16(const f32x4 v, unsigned char* dst) {
+static __device__ __forceinline__ void split_store_f16(const f32x4 v, unsigned char* dst, float& amax) {
     unsigned h0, l0, h1, l1;
+    watch2(amax, f32x2{v[0], v[1]});
+    watch2(amax, f32x2{v[2], v[3]});
     split2_pair(f32x2{v[0], v[1]}, h0, l0);
     split2_pair(f32x2{v[2], v[3]}, h1, l1);
     *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
@@ -160,8 +174,12 @@ static __device__ __forceinline__ void split_store_f16(const f32x4 v, unsigned c
 }
 
 // 8 consecutive fp32 (two 16-byte loads) -> the two fp16 planes of an MFMA operand fragment
-static __device__ __forceinline__ void split8_f16(const f32x4 v0, const f32x4 v1, u32x4& hi, u32x4& lo) {
+static __device__ __forceinline__ void split8_f16(const f32x4 v0, const f32x4 v1, u32x4& hi, u32x4& lo, float& amax) {
     unsigned h[4], l[4];
+    watch2(amax, f32x2{v0[0], v0[1]});
+    watch2(amax, f32x2{v0[2], v0[3]});
+    watch2(amax, f32x2{v1[0], v1[1]});
+    watch2(amax, f32x2{v1[2], v1[3]});
     split2_pair(f32x2{v0[0], v0[1]}, h[0], l[0]);
     split2_pair(f32x2{v0[2], v0[3]}, h[1], l[1]);
     split2_pair(f32x2{v1[0], v1[1]}, h[2], l[2]);

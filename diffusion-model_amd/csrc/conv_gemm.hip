@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
 template <int BN, int MODE, bool DUAL, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p) {
     if constexpr (F16) fp16_saturate();
+    float amax = 0.f;                         // F16: largest magnitude this thread has turned into an fp16 pair
     constexpr int TN = BN / 64;               // 32-column MFMA tiles per wave (2 x 2 waves)
     constexpr int NB = (BN * 6 + 255) / 256;  // 16-byte weight pieces per thread and step
 
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
             unsigned char* sB = smem[buf] + BM * XROW;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                if constexpr (F16) split_store_f16(areg[i], sA + (lrow + 64 * i) * XROW + lq * 8);
+                if constexpr (F16) split_store_f16(areg[i], sA + (lrow + 64 * i) * XROW + lq * 8, amax);
                 else split_store(areg[i], sA + (lrow + 64 * i) * XROW + lq * 8);
             }
 #pragma unroll
@@ -667,6 +668,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
             }
         }
     }
+    if constexpr (F16) raise_range_flag(p.range_flag, amax);
 }
 
 using ddpm::split_math;
@@ -706,6 +708,7 @@ int launch_gemm(GemmParams& p, hipStream_t s) {
     const bool dual = p.c2 > 0;
     if (x3) {
         const bool f16 = ddpm::f16_math();
+        if (f16 && !p.range_flag) return DDPM_E_LAUNCH;
         if (best_bn == 128) {
             if (dual) f16 ? conv_gemm_x3_kernel<128, MODE, true, true><<<g, b, 0, s>>>(p) : conv_gemm_x3_kernel<128, MODE, true, false><<<g, b, 0, s>>>(p);
             else f16 ? conv_gemm_x3_kernel<128, MODE, false, true><<<g, b, 0, s>>>(p) : conv_gemm_x3_kernel<128, MODE, false, false><<<g, b, 0, s>>>(p);
@@ -774,6 +777,7 @@ void fill_common(GemmParams& p, const ddpm_conv_desc* d, const float* src1, cons
     p.off_x = 0;
     p.stat_partial = nullptr;
     p.stat_blocks = 0;
+    p.range_flag = f16_math() ? ddpm::range_flag() : nullptr;   // (null on failure: the launchers of the fp16-pair kernels refuse)
     p.kc = (p.ctot + BK - 1) / BK;
     p.m_total = d->batch * d->in_h * d->in_w;
     p.src1_pixels = static_cast<long long>(d->batch) * d->in_h * d->in_w;
@@ -826,9 +830,10 @@ __global__ void pack_convT_dgrad_kernel(const float* __restrict__ w, int cin, in
 
 // Element i of the fragment-major packed image (i >> 9 = the 3 KiB block, i & 511 = position in a plane): three
 // bf16 planes, or -- fp16 pair scheme -- hi and scaled remainder in planes 0 and 1, plane 2 unused.
-__device__ __forceinline__ void store_split_element(unsigned short* out, int64_t i, float v, int f16) {
+__device__ __forceinline__ void store_split_element(unsigned short* out, int64_t i, float v, int f16, unsigned* range_flag) {
     unsigned short* o = out + (i >> 9) * 1536 + (i & 511);
     if (f16) {
+        raise_range_flag(range_flag, __builtin_fabsf(v));   // a weight beyond fp16's range is clipped like any operand
         const _Float16 h = static_cast<_Float16>(v);
         const _Float16 l = static_cast<_Float16>((v - static_cast<float>(h)) * kLoScale);
         o[0] = __builtin_bit_cast(unsigned short, h);
@@ -854,6 +859,7 @@ struct SplitPack {
     unsigned short* out;
     int taps, rows, cin, kc16, nbp, nq, f16;
     long long base, st, sq, sn, sc;
+    unsigned* range_flag;
 };
 
 __global__ void pack_split_kernel(const SplitPack a) {
@@ -872,7 +878,7 @@ __global__ void pack_split_kernel(const SplitPack a) {
         const int c = kc * 16 + (fl >> 5) * 8 + j;
         float v = 0.f;
         if (c < a.cin && n < a.rows) v = a.w[a.base + tap * a.st + (n / a.nq) * a.sq + (n % a.nq) * a.sn + c * a.sc];
-        store_split_element(a.out, i, v, a.f16);
+        store_split_element(a.out, i, v, a.f16, a.range_flag);
     }
 }
 
@@ -883,6 +889,7 @@ struct QkvPack {
     const float *qw, *kw, *vw, *qb, *kb, *vb;
     float *out_f, *out_t, *bias;
     int c, dq, dqp, split, f16;
+    unsigned* range_flag;
 };
 
 __device__ __forceinline__ float qkv_weight(const QkvPack& a, int n, int ch) {
@@ -902,7 +909,7 @@ __global__ void pack_qkv_kernel(const QkvPack a) {
             const int j = static_cast<int>(i & 7), fl = static_cast<int>((i >> 3) & 63);
             const int nb = static_cast<int>((i >> 9) % nbp), kc = static_cast<int>((i >> 9) / nbp);
             const int n = nb * 32 + (fl & 31), ch = kc * 16 + (fl >> 5) * 8 + j;
-            store_split_element(reinterpret_cast<unsigned short*>(a.out_f), i, (n < lq && ch < a.c) ? qkv_weight(a, n, ch) : 0.f, a.f16);
+            store_split_element(reinterpret_cast<unsigned short*>(a.out_f), i, (n < lq && ch < a.c) ? qkv_weight(a, n, ch) : 0.f, a.f16, a.range_flag);
         }
         // transpose: rows = c, depth = lq
         const int nbt = (a.c + 31) / 32, kct = (lq + 15) / 16;
@@ -910,7 +917,7 @@ __global__ void pack_qkv_kernel(const QkvPack a) {
             const int j = static_cast<int>(i & 7), fl = static_cast<int>((i >> 3) & 63);
             const int nb = static_cast<int>((i >> 9) % nbt), kc = static_cast<int>((i >> 9) / nbt);
             const int ch = nb * 32 + (fl & 31), n = kc * 16 + (fl >> 5) * 8 + j;
-            store_split_element(reinterpret_cast<unsigned short*>(a.out_t), i, (n < lq && ch < a.c) ? qkv_weight(a, n, ch) : 0.f, a.f16);
+            store_split_element(reinterpret_cast<unsigned short*>(a.out_t), i, (n < lq && ch < a.c) ? qkv_weight(a, n, ch) : 0.f, a.f16, a.range_flag);
         }
     } else {
         for (int64_t i = t0; i < static_cast<int64_t>(lq) * a.c; i += stride) {
@@ -941,6 +948,7 @@ SplitPack make_split_pack(const float* w, float* out, int taps, int rows, int ci
     a.nbp = (rows + 31) / 32;
     a.nq = nq;
     a.f16 = f16_math() ? 1 : 0;
+    a.range_flag = a.f16 ? ddpm::range_flag() : nullptr;
     a.base = base;
     a.st = st;
     a.sq = sq;
@@ -972,7 +980,7 @@ __global__ void pack_split_batch_kernel(const SplitPackBatch b) {
         const int c = kc * 16 + (fl >> 5) * 8 + j;
         float v = 0.f;
         if (c < a.cin && n < a.rows) v = a.w[a.base + tap * a.st + (n / a.nq) * a.sq + (n % a.nq) * a.sn + c * a.sc];
-        store_split_element(a.out, i, v, a.f16);
+        store_split_element(a.out, i, v, a.f16, a.range_flag);
     }
 }
 
@@ -988,11 +996,13 @@ int launch_split_pack(const float* w, float* out, int taps, int rows, int cin, i
     a.nbp = (rows + 31) / 32;
     a.nq = nq;
     a.f16 = f16_math() ? 1 : 0;
+    a.range_flag = a.f16 ? ddpm::range_flag() : nullptr;
     a.base = base;
     a.st = st;
     a.sq = sq;
     a.sn = sn;
     a.sc = sc;
+    if (a.f16 && !a.range_flag) return DDPM_E_LAUNCH;
     const int64_t total = static_cast<int64_t>(taps) * a.kc16 * a.nbp * 512;
     const int grid = static_cast<int>((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     pack_split_kernel<<<grid, 256, 0, s>>>(a);
@@ -1038,6 +1048,8 @@ extern "C" int ddpm_pack_qkv(const float* qw, const float* kw, const float* vw, 
     a.c = c; a.dq = dq; a.dqp = dqp;
     a.split = split_math() ? 1 : 0;
     a.f16 = f16_math() ? 1 : 0;
+    a.range_flag = a.f16 ? ddpm::range_flag() : nullptr;
+    if (a.f16 && !a.range_flag) return DDPM_E_LAUNCH;
     const int64_t total = static_cast<int64_t>(2 * dqp + c + 31) * (c + 31);
     const int grid = static_cast<int>((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     pack_qkv_kernel<<<grid, 256, 0, as_stream(stream)>>>(a);
@@ -1155,6 +1167,7 @@ extern "C" int ddpm_pack_conv3x3_batch(int n, const float* const* w, const int* 
             const int i = i0 + (k < cnt ? k : 0);      // unused slots repeat the first item (never selected: gridDim.y = cnt)
             b.item[k] = flip[i] ? make_split_pack(w[i], out[i], 9, cin[i], cout[i], cin[i], 8, -1, 0, 9, 9ll * cin[i])
                                 : make_split_pack(w[i], out[i], 9, cout[i], cin[i], cout[i], 0, 1, 0, 9ll * cin[i], 9);
+            if (b.item[k].f16 && !b.item[k].range_flag) return DDPM_E_LAUNCH;
             const int64_t total = 9ll * b.item[k].kc16 * b.item[k].nbp * 512;
             if (k < cnt && total > most) most = total;
         }

@@ -44,6 +44,7 @@ struct WgradParams {
     int m_tiles, n_tiles;
     int work;                 // workgroups with work (the grid is rounded up to a multiple of 8)
     int tap_groups;           // work items along the tap axis: taps, or ceil(taps / 2) when a tile holds two taps
+    unsigned* range_flag;     // fp16-pair kernel: raised when an operand lies beyond fp16's range
 };
 
 constexpr unsigned OOB = 0x80000000u;  // offsets at or beyond the buffer descriptor's range read as zero
@@ -254,8 +255,10 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst) 
     *reinterpret_cast<u32x2*>(dst + 2 * XPLANE) = lo;
 }
 
-__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst) {
+__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, float& amax) {
     unsigned h0, l0, h1, l1;
+    ddpm::conv::watch2(amax, f32x2{v[0], v[1]});
+    ddpm::conv::watch2(amax, f32x2{v[2], v[3]});
     ddpm::conv::split2_pair(f32x2{v[0], v[1]}, h0, l0);
     ddpm::conv::split2_pair(f32x2{v[2], v[3]}, h1, l1);
     *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
@@ -275,6 +278,7 @@ template <int MODE, int PAIR, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams p) {
     static_assert(PAIR == 0 || MODE == WG_CONV3, "two taps per tile exist for the 3x3 convolution only");
     if constexpr (F16) ddpm::conv::fp16_saturate();
+    float amax = 0.f;                     // F16: largest magnitude this thread has turned into an fp16 pair
     constexpr int BT = 128;
     constexpr int NPL = F16 ? 2 : 3;      // operand planes
     constexpr int F4R = BT / 4;           // float4 per tile row
@@ -412,8 +416,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
         for (int i = 0; i < LPT; ++i) {
             const int off = (row0 + RSTEP * i) * XROWB + c4 * 8;
             if constexpr (F16) {
-                split4_store_f16(areg[set][i], &sA[buf][off]);
-                split4_store_f16(breg[set][i], &sB[buf][off]);
+                split4_store_f16(areg[set][i], &sA[buf][off], amax);
+                split4_store_f16(breg[set][i], &sB[buf][off], amax);
             } else {
                 split4_store(areg[set][i], &sA[buf][off]);
                 split4_store(breg[set][i], &sB[buf][off]);
@@ -464,6 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const f32x2 xv = {x[2 * q], x[2 * q + 1]};
+                        ddpm::conv::watch2(amax, xv);
                         const f16x2 hh = __builtin_convertvector(xv, f16x2);
                         hi2[v][q] = __builtin_bit_cast(unsigned, hh);
                         rem[v][q] = (xv - __builtin_convertvector(hh, f32x2)) * kLoScale;
@@ -589,6 +594,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
             for (int j = 0; j < 2; ++j) master[i][j] = acc[i][j] + master[i][j] * kLoInv;
     }
 
+    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, amax);
     if (wave_tap >= p.taps) return;
     float* outp = p.out + static_cast<int64_t>(wave_tap) * p.m_total * p.n_total;
 #pragma unroll
@@ -666,6 +672,8 @@ int launch_wgrad(WgradParams& p, hipStream_t s) {
     const int64_t grid = (tiles * splits + 7) / 8 * 8;
     if (int rc = clear_accumulator(p.out, static_cast<int64_t>(p.taps) * p.m_total * p.n_total, s)) return rc;
     const bool f16 = ddpm::f16_math();
+    p.range_flag = f16 ? ddpm::range_flag() : nullptr;
+    if (f16 && !p.range_flag) return DDPM_E_LAUNCH;
     if constexpr (MODE == WG_CONV3) {
         if (pair == 1) {
             if (f16) conv_wgrad_x3_kernel<MODE, 1, true><<<static_cast<unsigned>(grid), 256, 0, s>>>(p);

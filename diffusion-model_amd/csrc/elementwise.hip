@@ -454,8 +454,6 @@ extern "C" int ddpm_scale_tensors(int ntensors, float* const* tensors, const int
     return ddpm::check_launch("scale_tensors_kernel");
 }
 
-extern "C" int ddpm_conv_math(void) { return ddpm::conv_math(); }
-
 extern "C" int ddpm_pool_skip_fwd(const float* x, int ldx, const float* temb, float* skip, int lds_, float* pooled, int ldp,
                                   uint8_t* argmax, int batch, int h, int w, int c, void* stream) {
     DDPM_REQUIRE(x && batch > 0 && h > 0 && w > 0 && c > 0 && (c & 3) == 0 && (ldx & 3) == 0);

@@ -10,12 +10,13 @@ second-iteration/unet.py:118-158, third-iteration/unet.py:126-178.
 """
 import ctypes as C
 import os
+import warnings
 import weakref
 
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, EmbedArgs, Epilogue, call, conv_math, packed_floats
+from ._lib import ConvDesc, EmbedArgs, Epilogue, call, conv_math, math_scope, packed_floats
 from .engine_train import TrainMixin, UNetFunction
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
@@ -84,6 +85,13 @@ class UNetEngine(TrainMixin):
         self.num_classes = num_classes
         self._cache = {}
         self._tensors = None
+        # Arithmetic of this network's MFMA-fed kernels: None = the library's current mode (DDPM_CONV_MATH, default the
+        # fp16 pair); 'bf16x3' once an operand beyond fp16's range has been seen (range_fallback), or set by the caller.
+        self.math = None
+        self.range_fallbacks = 0       # how often this network has left the fp16 pair because of such an operand
+        self._range_pending = None     # (event, slot): a flag read-back enqueued and not yet examined
+        self._range_host = None        # pinned int32 words the read-backs land in
+        self._labels_pending = []      # deferred label range checks of training steps: (event, pinned verdict, classes)
         self.prof = None       # when a list: (kernel label, flops, start event, end event) per sampled MFMA launch
         self.prof_stride = 1   # every prof_stride-th MFMA launch is bracketed by events (a stride that does not
         self._prof_i = 0       # divide the launches per step walks through all launch sites over the steps)
@@ -126,7 +134,91 @@ class UNetEngine(TrainMixin):
         self._cache.clear()
         self._tensors = None
 
+    # ------------------------------------------------------------------ arithmetic and its range watch
+    def math_scope(self):
+        """Context in which the library computes in this network's arithmetic."""
+        return math_scope(self.math)
+
+    def effective_math(self):
+        return self.math or conv_math()
+
+    def range_watching(self):
+        """True while this network computes with fp16 pairs, whose operands are clipped beyond +-65504: the kernels
+        raise a device flag when that happens and the host mirror reacts (DDPM_RANGE_WATCH=0 switches the reaction
+        off: results are then clipped silently, as a diagnostic). Not while a HIP graph is being captured: the flag's
+        read-back and the event query are not capturable, so a replayed graph runs without the watch."""
+        return (self.effective_math() == "f16x2" and os.environ.get("DDPM_RANGE_WATCH", "1") != "0"
+                and not torch.cuda.is_current_stream_capturing())
+
+    def _range_slot(self):
+        if self._range_host is None:
+            self._range_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        return self._range_host
+
+    def range_clear(self):
+        """Forget whatever raised the flag before this point of the current stream."""
+        call("ddpm_range_flag_read", None, 1, _stream())
+
+    def range_check_sync(self):
+        """Read and clear the flag behind everything enqueued so far and WAIT for it: True when one of the kernels
+        since the last clear met an operand beyond fp16's range."""
+        host = self._range_slot()
+        call("ddpm_range_flag_read", C.c_void_p(host.data_ptr()), 1, _stream())
+        torch.cuda.current_stream().synchronize()
+        return bool(host[0].item())
+
+    def range_post(self):
+        """Enqueue a read-and-clear of the flag without waiting; range_poll examines it once the GPU has got there.
+        (While one is pending no second one is enqueued: the flag stays raised on the device until it is read.)"""
+        if self._range_pending is not None:
+            return
+        host = self._range_slot()
+        call("ddpm_range_flag_read", C.c_void_p(host.data_ptr() + 4), 1, _stream())
+        ev = torch.cuda.Event()
+        ev.record()
+        self._range_pending = ev
+
+    def range_poll(self):
+        """Examine a pending read-back if the GPU has finished it (never waits). An operand beyond fp16's range
+        moves this network to the three-plane bf16 arithmetic for every later call, with a warning."""
+        ev = self._range_pending
+        if ev is None or not ev.query():
+            return
+        self._range_pending = None
+        if int(self._range_host[1].item()):
+            self.range_fallback("an earlier call")
+
+    def range_fallback(self, where):
+        self.math = "bf16x3"
+        self.range_fallbacks += 1
+        warnings.warn(f"diffusion_model_amd: {where} met activations, weights or gradients beyond +-65504, which the default "
+                      "fp16-pair arithmetic clips; this network now computes with three bf16 planes per operand (full fp32 "
+                      "range, about 1.5x slower). Set DDPM_CONV_MATH=bf16x3 to start there.", RuntimeWarning, stacklevel=3)
+
+    def _poll_labels(self):
+        """Deferred label checks of earlier training steps whose verdict has arrived (never waits)."""
+        pending, self._labels_pending = self._labels_pending, []
+        for i, (ev, host, n_classes) in enumerate(pending):
+            if not ev.query():
+                self._labels_pending = pending[i:]
+                return
+            if int(host.item()):
+                self._labels_pending = pending[i + 1:]
+                raise IndexError(f"label out of range: an earlier training step was handed a label outside [0, {n_classes}) "
+                                 "(the embedding's classes); that sample's outputs and the step's loss were NaN")
+
     def run(self, x, t, y, training):
+        if self._labels_pending and not torch.cuda.is_current_stream_capturing():
+            self._poll_labels()
+        if self.range_watching():
+            self.range_poll()
+        with self.math_scope():
+            out = self._run(x, t, y, training)
+        if self.range_watching() and not (torch.is_grad_enabled() and training):
+            self.range_post()      # (a differentiated training forward posts after its backward)
+        return out
+
+    def _run(self, x, t, y, training):
         if x.dtype != torch.float32:
             x = x.float()
         t = t.to(x.device)
@@ -158,7 +250,7 @@ class UNetEngine(TrainMixin):
             if self.num_classes is None:
                 raise AttributeError("this UNet was built without num_classes; it has no label embedding")
             y = y.to(device=x.device, dtype=torch.int64).contiguous()
-        with torch.no_grad():
+        with torch.no_grad(), self.math_scope():
             return self.forward_eval(x, t, y, step=step)
 
     # ------------------------------------------------------------------ parameters and caches
@@ -170,14 +262,17 @@ class UNetEngine(TrainMixin):
         return self._tensors[key]
 
     def _cached(self, kind, keys, build):
+        """Value derived from parameters, rebuilt when one of them changes. Packed weights belong to the arithmetic
+        they were packed in, so the library's current mode is part of the key (both copies are kept)."""
         ts = [self.T(k) for k in keys]
         stamp = tuple((t._version, t.data_ptr()) for t in ts)
-        hit = self._cache.get((kind, keys[0]))
+        slot = (kind, keys[0], conv_math())
+        hit = self._cache.get(slot)
         if hit is not None and hit[0] == stamp:
             return hit[1]
         with torch.no_grad():
             val = build(*ts)
-        self._cache[(kind, keys[0])] = (stamp, val)
+        self._cache[slot] = (stamp, val)
         return val
 
     def packed_conv3(self, key, flip=False):
@@ -194,8 +289,9 @@ class UNetEngine(TrainMixin):
         launches of a few microseconds each). The packed buffers are refilled in place (same stream: kernels enqueued
         earlier still see the old contents)."""
         items = []
-        for (kind, key), (stamp, val) in self._cache.items():
-            if kind in ("pk3", "pk3f"):
+        mode = conv_math()
+        for (kind, key, packed_in), (stamp, val) in self._cache.items():
+            if kind in ("pk3", "pk3f") and packed_in == mode:
                 w = self.T(key)
                 now = ((w._version, w.data_ptr()),)
                 if now != stamp and w.is_contiguous():
@@ -210,7 +306,7 @@ class UNetEngine(TrainMixin):
         flip = (C.c_int * n)(*[int(it[0] == "pk3f") for it in items])
         call("ddpm_pack_conv3x3_batch", n, ptrs, cout, cin, flip, outs, _stream())
         for kind, key, _, val, now in items:
-            self._cache[(kind, key)] = (now, val)
+            self._cache[(kind, key, mode)] = (now, val)
 
     def packed_convT(self, key):
         def build(w):
@@ -306,7 +402,7 @@ class UNetEngine(TrainMixin):
         b, h, w = x.bhw
         call("ddpm_add_temb", x.ptr, x.ld, _ptr(temb), out.ptr, out.ld, b, h * w, x.c, _stream())
 
-    def time_embed(self, t, y, emb_out=None):
+    def time_embed(self, t, y, emb_out=None, defer_label_check=False):
         B = t.shape[0]
         dev = t.device
         chans = [self.base, self.base * 2, self.base * 4, self.base * 8]
@@ -330,7 +426,7 @@ class UNetEngine(TrainMixin):
             if y.numel() not in (1, B):
                 raise RuntimeError(f"label tensor of {y.numel()} entries cannot broadcast over a batch of {B}")
             table = self.T("label_embedding.weight")
-            self._check_labels(y, table.shape[0])
+            self._check_labels(y, table.shape[0], defer_label_check)
             keep.append(y)
             a.n_labels = y.numel()
             a.n_classes = table.shape[0]
@@ -350,12 +446,23 @@ class UNetEngine(TrainMixin):
         call("ddpm_time_embed", C.byref(a), _stream())
         return outs
 
-    def _check_labels(self, y, n_classes):
+    def _check_labels(self, y, n_classes, defer=False):
         """nn.Embedding raises for a label outside [0, num_classes) (third-iteration/unet.py:136); so does this, with
         one device->host read per DISTINCT label tensor: the sampling loop hands the same tensor to every one of its
-        T steps and pays once. (The kernels never dereference such a label either way.)"""
+        T steps and pays once. (The kernels never dereference such a label either way: that sample's embedding rows
+        are NaN.) A training step brings a fresh label tensor every time, and a read there would stall the host at
+        the start of every forward: with `defer` the verdict is copied to pinned memory behind the step's kernels and
+        examined, without waiting, at the start of a later call, which then raises."""
         seen = getattr(self, "_labels_ok", None)      # (weak reference to the tensor object, its version, class count)
         if seen is not None and seen[0]() is y and seen[1:] == (y._version, n_classes):
+            return
+        if defer:
+            bad = ((y < 0) | (y >= n_classes)).any().to(torch.int32).view(1)
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(bad, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._labels_pending.append((ev, host, n_classes))
             return
         lo, hi = torch.aminmax(y)
         if int(lo) < 0 or int(hi) >= n_classes:

@@ -32,7 +32,9 @@ def _dist_active():
 
 
 class TrainMixin:
-    sync_bn = False     # data-parallel training: BatchNorm over the GLOBAL batch (statistics all-reduced across ranks)
+    sync_bn = False     # data-parallel training: BatchNorm over the GLOBAL batch (statistics all-reduced across ranks;
+                        # every rank must hold the same number of samples: the global row count is local rows x world size)
+    dist_group = None   # process group of those all-reduces (None = the default group); BucketedGradientAverager.attach sets it
     grad_sink = None    # data-parallel training: where the backward puts parameter gradients (parallel.BucketedGradientAverager)
     _s2 = None                                                      # second stream of the backward pass (weight gradients)
     _main_stream = None                                             # the stream the backward itself runs on (set when _s2 is used)
@@ -114,8 +116,8 @@ class TrainMixin:
             from . import parallel
             sums = torch.empty(2 * cout, device=dev, dtype=torch.float64)
             call("ddpm_bn_partial_sums", raw.ptr, raw.ld, stat_rows, cout, _ptr(self._workspace(dev)), _ptr(sums), _stream())
-            parallel.all_reduce_(sums)
-            stat_rows = stat_rows * parallel.world_size()
+            parallel.all_reduce_(sums, group=self.dist_group)
+            stat_rows = stat_rows * parallel.world_size(self.dist_group)
             call("ddpm_bn_finalize_stats", _ptr(sums), stat_rows, cout, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
                  _ptr(self.T(bn_key + ".running_mean")), _ptr(self.T(bn_key + ".running_var")), _stream())
         else:
@@ -162,7 +164,7 @@ class TrainMixin:
         self.prepack_conv3()          # every 3x3 weight the optimizer has changed, both orientations, in one launch
         bc, v1 = self.base, self.v == 1
         emb = torch.empty((B, self.emb // 2 * 2), device=dev, dtype=torch.float32)
-        temb = self.time_embed(t, y, emb_out=emb)
+        temb = self.time_embed(t, y, emb_out=emb, defer_label_check=True)   # no host wait inside a training step
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         fms = []
         tape = dict(x=x, t=t, y=y, emb=emb, shape=(B, H, W))
@@ -275,7 +277,7 @@ class TrainMixin:
                  _ptr(self.T(bn + ".weight")), _ptr(self.T(bn + ".bias")), rec["act"], rows, cout, _ptr(ws), _ptr(sums), _stream())
             db.copy_(sums[:cout])                              # this rank's share of the parameter gradients
             dw.copy_(sums[cout:])
-            parallel.all_reduce_(sums)
+            parallel.all_reduce_(sums, group=self.dist_group)
             call("ddpm_bn_bwd_apply", raw.ptr, raw.ld, dout.ptr, dout.ld, rp, rl, _ptr(rec["mean"]), _ptr(rec["invstd"]),
                  _ptr(self.T(bn + ".weight")), _ptr(self.T(bn + ".bias")), _ptr(sums.float()), rec["stat_rows"], rec["act"], rows, cout,
                  _ptr(ws), draw.ptr, draw.ld, dp, dl, _ptr(dcb), _stream())
@@ -371,11 +373,13 @@ class TrainMixin:
         ws = self._workspace(dev)
         dout = dout.contiguous()
         self._gall = []
-        # fp16-pair arithmetic: the backward runs on the incoming gradient times the power of two that brings its
-        # largest magnitude into [1, 2) (loss gradients are far below fp16's exponent range), and every parameter
-        # gradient is multiplied by the inverse at the end; both are exact in fp32. Ranks of a data-parallel job
-        # agree on the scale first: their gradients (and global-batch BatchNorm sums) are added to each other.
-        scaled = conv_math() == "f16x2"
+        # The backward runs on the incoming gradient times the power of two that brings its largest magnitude into
+        # [1, 2) (loss gradients are far below fp16's exponent range, which the fp16-pair arithmetic needs its operands
+        # in), and every parameter gradient is multiplied by the inverse at the end; both are exact in fp32. The
+        # three-plane bf16 arithmetic does not need it but does the same, so that the ranks of a data-parallel job issue
+        # the same collectives whichever of the two each of them is in. Ranks agree on the scale first: their
+        # gradients (and global-batch BatchNorm sums) are added to each other.
+        scaled = conv_math() != "fp32"
         if scaled:
             if self._gstate is None or self._gstate.device != dev:
                 self._gstate = torch.zeros(3, device=dev, dtype=torch.float32)
@@ -384,7 +388,7 @@ class TrainMixin:
             if _dist_active():
                 import torch.distributed as dist
                 from . import parallel
-                parallel.all_reduce_(st[0:1], op=dist.ReduceOp.MAX)
+                parallel.all_reduce_(st[0:1], op=dist.ReduceOp.MAX, group=self.dist_group)
             d2 = torch.empty_like(dout)
             call("ddpm_grad_scale", _ptr(dout), dout.numel(), _ptr(st), _ptr(d2), _stream())
             dout = d2
@@ -515,7 +519,10 @@ class UNetFunction(torch.autograd.Function):
         if dout is None:                   # nothing downstream depends on the prediction
             return (None,) * (5 + len(ctx.names))
         eng = ctx.engine
-        grads = eng.backward(ctx.tape, dout)
+        with eng.math_scope():
+            grads = eng.backward(ctx.tape, dout)
+        if eng.range_watching():
+            eng.range_post()       # examined at the start of the next call (no host wait here)
         ctx.tape = None
         sink = eng.grad_sink
         if sink is not None and sink.takes_over(grads):

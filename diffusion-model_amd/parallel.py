@@ -73,30 +73,43 @@ def average_gradients(params, group=None):
         off += n
 
 
-_rng_checked = False
+def _generator_digests(device):
+    """(state of torch's CPU generator, state of the generator of `device` if it is a GPU), as hashable digests."""
+    import hashlib
+    cpu = hashlib.sha1(torch.get_rng_state().numpy().tobytes()).hexdigest()
+    dev = torch.device(device)
+    gpu = None
+    if dev.type == "cuda":
+        gpu = hashlib.sha1(torch.cuda.get_rng_state(dev).numpy().tobytes()).hexdigest()
+    return cpu, gpu
 
 
 def decorrelate_rng(device, group=None):
     """Make sure no two ranks draw the same noise. Scripts usually seed every process alike (torch.manual_seed(0)), and
-    ranks that then draw their own x_T and z would all produce the SAME samples. Once per process: the ranks compare
-    the seeds of the generator that torch.randn on `device` uses; if any two agree, every rank reseeds that generator
-    with seed + rank (rank 0 keeps the sequence a single process would have had)."""
-    global _rng_checked
+    ranks that then draw their own x_T and z would all produce the SAME samples. sample() draws x_T -- and, with
+    in_kernel_noise, the seed of the per-step noise -- from torch's CPU generator and the per-step noise from the
+    generator of `device`, so BOTH are compared: the ranks exchange digests of the generators' current states, and
+    every rank whose state another rank shares reseeds that generator with (its seed + rank); rank 0 keeps the sequence
+    a single process would have had. Called before every sharded sampling call that draws its own noise: a script
+    that reseeds all ranks alike between two calls is caught again. Returns the names of the generators reseeded."""
     world, rank = _world(group)
-    if _rng_checked or world == 1:
-        return
-    _rng_checked = True
+    if world == 1:
+        return ()
     dev = torch.device(device)
-    seed = torch.cuda.initial_seed() if dev.type == "cuda" else torch.initial_seed()
-    seeds = [None] * world
-    dist.all_gather_object(seeds, int(seed), group=group)
-    if len(set(seeds)) < world:
-        new = (int(seed) + rank) % (1 << 63)
-        if dev.type == "cuda":
+    mine = _generator_digests(dev)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine, group=group)
+    reseeded = []
+    if len({d[0] for d in everyone}) < world:
+        if rank:
+            torch.default_generator.manual_seed((int(torch.initial_seed()) + rank) % (1 << 63))
+        reseeded.append("cpu")
+    if dev.type == "cuda" and len({d[1] for d in everyone}) < world:
+        if rank:
             with torch.cuda.device(dev):
-                torch.cuda.manual_seed(new)
-        else:
-            torch.default_generator.manual_seed(new)
+                torch.cuda.manual_seed((int(torch.cuda.initial_seed()) + rank) % (1 << 63))
+        reseeded.append("cuda")
+    return tuple(reseeded)
 
 
 def sample_sharded(diffusion, x_shape, device, gather=True, noise=None, group=None, **sample_kwargs):
@@ -164,6 +177,7 @@ class BucketedGradientAverager:
 
     def attach(self):
         self.engine.grad_sink = self
+        self.engine.dist_group = self.group     # global-batch BatchNorm and the gradient scale reduce over the same ranks
         return self
 
     def detach(self):

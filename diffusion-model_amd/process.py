@@ -98,7 +98,23 @@ class _DiffusionBase:
         if philox and not fused:
             raise RuntimeError("in_kernel_noise needs this package's UNet in eval mode (the noise is drawn by its fused last kernel)")
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if philox else 0
-        for t in reversed(range(T)):
+        # Range watch (fp16-pair arithmetic only): the kernels raise a device flag when an operand lies beyond fp16's
+        # range, which the pair clips where fp32 does not. The flag is read at every stage hand-off; if it is up, the
+        # steps since the previous hand-off are repeated from a saved copy of x_t (same noise: the generator's state is
+        # restored) with three bf16 planes per operand, and the network stays there. A trained network keeps x_t at
+        # unit scale and never gets here; an untrained one whose samples grow without bound does.
+        eng = getattr(self.model, "_engine", None)
+        watch = eng is not None and eng.range_watching()
+        ckpt = None
+        if watch:
+            eng.range_poll()
+            watch = eng.range_watching()
+        if watch:
+            eng.range_clear()
+            ckpt = self._checkpoint(x_t, T - 1, zi, len(stages))
+        t = T
+        while t > 0:
+            t -= 1
             t_tensor = torch.full((x_shape[0],), t, dtype=torch.long, device=x_t.device)
             c1, c2, c3 = step_coefficients_host(self._betas_h[t], self._alphas_h[t], self._abar_h[t])
             z = None
@@ -130,6 +146,14 @@ class _DiffusionBase:
             if x_t.shape != x_shape:
                 raise ValueError(f"Unexpected shape after update: {x_t.shape}, expected: {x_shape}")
             if t % (T // 10) == 0 or t == 0:
+                if watch:
+                    if eng.range_check_sync():
+                        eng.range_fallback("sample()")
+                        x_t, t, zi, keep = self._restore(ckpt)
+                        del stages[keep:]
+                        watch = False
+                        continue
+                    ckpt = self._checkpoint(x_t, t - 1, zi, len(stages) + 1)
                 # stage hand-off (the reference's x_t.clone().detach().cpu()): an asynchronous copy into pinned
                 # memory, ordered on the stream behind the step that produced x_t; one wait at the end instead
                 # of one per stage
@@ -139,6 +163,20 @@ class _DiffusionBase:
         self._final_on_device = x_t
         torch.cuda.current_stream(x_t.device).synchronize()
         return stages
+
+    @staticmethod
+    def _checkpoint(x_t, t_next, zi, nstages):
+        """What a repeat of the steps from t_next on needs: x_t, the position in an injected noise list, the stages
+        handed over so far and the state of the device generator that torch.randn_like draws the per-step noise from."""
+        dev = x_t.device
+        rng = torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None
+        return dict(x=x_t.clone(), t=t_next, zi=zi, nstages=nstages, rng=rng, dev=dev)
+
+    @staticmethod
+    def _restore(ckpt):
+        if ckpt["rng"] is not None:
+            torch.cuda.set_rng_state(ckpt["rng"], ckpt["dev"])
+        return ckpt["x"], ckpt["t"] + 1, ckpt["zi"], ckpt["nstages"]
 
     def sample_images(self, x_shape, device='cpu', **kwargs):
         """One batch of finished images in [0, 1] on the host: sample() followed by the callers' `(x + 1) / 2` and

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ._lib import ConvDesc, Epilogue, call, lib, packed_floats
+from ._lib import ConvDesc, Epilogue, call, conv_math, lib, packed_floats
 
 ACT_NONE, ACT_RELU = 0, 1
 
@@ -45,7 +45,7 @@ class SimpleCNN(nn.Module):
         return out
 
     def _cached(self, name, tensor, build):
-        stamp = (tensor._version, tensor.data_ptr())
+        stamp = (tensor._version, tensor.data_ptr(), conv_math())     # packed weights belong to the arithmetic they were packed in
         hit = self._packed.get(name)
         if hit is None or hit[0] != stamp:
             with torch.no_grad():

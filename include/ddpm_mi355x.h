@@ -142,10 +142,24 @@ int ddpm_grad_amax(const float* g, int64_t n, float* state, void* stream);
 int ddpm_grad_scale(const float* g, int64_t n, float* state, float* out, void* stream);
 int ddpm_scale_tensors(int ntensors, float* const* tensors, const int64_t* numel, const float* factor, void* stream);
 
-/* Arithmetic of the MFMA-fed convolutions in this process (DDPM_CONV_MATH in the environment, read once):
- * 0 fp32 MFMA, 1 three bf16 planes per operand and six cross products, 2 fp16 pair and three cross products.
- * The packed-weight format follows it. No counterpart in the reference (torch picks its own kernels). */
+/* Arithmetic of the MFMA-fed convolutions and attention kernels: 0 fp32 MFMA, 1 three bf16 planes per operand and
+ * six cross products, 2 fp16 pair and three cross products (the default). The process starts in the mode that
+ * DDPM_CONV_MATH names in the environment ("fp32", "bf16x3", "f16x2"); ddpm_set_conv_math changes it for every later
+ * call of the process (not thread-local). The packed-weight format follows the mode: weights must be used in the mode
+ * they were packed in. No counterpart in the reference (torch picks its own kernels; on a CPU it computes in IEEE fp32,
+ * first-iteration/unet.py:16-21 run without autocast). */
 int ddpm_conv_math(void);
+int ddpm_set_conv_math(int mode);
+
+/* Range watch of the fp16-pair arithmetic. An fp16 pair represents magnitudes up to 65504; an operand beyond that is
+ * clipped on its way into the matrix instructions (fp32, and mode 1, have no such limit). Every kernel that forms pairs
+ * -- the convolutions, weight gradients, attention forward and the weight-packing kernels in mode 2 -- raises a flag in
+ * device memory (one word per GPU, built into the library) when one of its operands was beyond that range, so that a
+ * caller can repeat the work in mode 1 instead of keeping a clipped result. ddpm_range_flag_read enqueues on `stream`
+ * a copy of the current GPU's flag into host_dst[0] (pinned host memory, or the copy is synchronous; may be NULL) and,
+ * when clear != 0, resets the flag behind it; the value is valid once the stream has reached that point. The host
+ * mirror does this at the stage hand-offs of sample() and once per training step. No counterpart in the reference. */
+int ddpm_range_flag_read(uint32_t* host_dst, int clear, void* stream);
 
 /* Adam update of ntensors tensors (host arrays of device pointers and element counts; the arrays are
  * consumed before the call returns): exp_avg = lerp(exp_avg, grad, 1-beta1); exp_avg_sq = beta2*exp_avg_sq
@@ -354,7 +368,8 @@ int ddpm_bn_stats_from_partials(const double* partial, int nblocks, int64_t rows
  * Results are bit-identical to ddpm_bn_stats. All calls on one GPU share that buffer: calls that
  * overlap on the same GPU (different streams or threads) race; calls ordered on one stream do not.
  * The first call on a device looks the buffer's address up (hipGetSymbolAddress) and should be made
- * outside a stream capture. */
+ * outside a stream capture. The buffer is the CURRENT device's: a `stream` of another device returns
+ * DDPM_E_INVALID (make the stream's device current first). */
 int ddpm_bn_stats_noalloc_max_channels(void);
 int ddpm_bn_stats_noalloc(const float* x, int ldx, int64_t rows, int c, float eps, float momentum,
                           float* mean, float* invstd, float* running_mean, float* running_var,

@@ -3,7 +3,8 @@ collectives through the host; the GPU work is the real HIP path). Checks, agains
   1. global-batch BatchNorm + averaged gradients of a sharded batch == the reference's full-batch gradients;
   2. the bucketed averager (recording step, then buckets from inside the backward) == the flat all-reduce;
   3. 10 Adam steps sharded 2 + 2 reproduce the reference's single-process loss trace (batch 4);
-  4. sharded sampling with sliced injected noise == unsharded sampling, bit for bit.
+  4. sharded sampling with sliced injected noise == unsharded sampling, bit for bit;
+  5. ranks that were seeded alike still draw different noise on the GPU (torch's generators and the in-kernel stream).
 Prints DP_WORKER_OK on rank 0."""
 import os
 import sys
@@ -133,6 +134,26 @@ def main():
         whole = dm3.sample(shape, "cuda", noise=(xT, zs), labels=labels, cfg_scale=1.5)
     assert [s[1] for s in sharded] == [s[1] for s in whole]
     assert all(torch.equal(a[0], b[0]) for a, b in zip(sharded, whole))
+
+    # ---- 5: ranks seeded alike must not produce the same samples -------------------------------------------------
+    # (x_T and the in-kernel noise seed come from torch's CPU generator, the per-step noise from the GPU's)
+    for in_kernel in (False, True):
+        for round_ in range(2):                      # the second round reseeds all ranks alike AGAIN: caught again
+            torch.manual_seed(0)                     # seeds the CPU and the GPU generator, the same on both ranks
+            with torch.no_grad():
+                both = parallel.sample_sharded(dm3, shape, "cuda", labels=labels, in_kernel_noise=in_kernel)
+            first, last = both[0][0], both[-1][0]    # whole batch, rank 0's samples first
+            assert first.shape[0] == shape[0]
+            assert not torch.equal(first[:2], first[2:]), ("same x_T / first-stage samples on both ranks", in_kernel, round_)
+            assert not torch.equal(last[:2], last[2:]), ("same final samples on both ranks", in_kernel, round_)
+    # rank 0 keeps the sequence a single process seeded the same way would have had
+    torch.manual_seed(0)
+    with torch.no_grad():
+        both = parallel.sample_sharded(dm3, shape, "cuda", labels=labels)
+        torch.manual_seed(0)
+        alone = dm3.sample((2,) + shape[1:], "cuda", labels=labels)
+    if rank == 0:
+        assert torch.equal(both[-1][0][:2], alone[-1][0])
 
     dist.barrier()
     if rank == 0:

@@ -203,35 +203,6 @@ def test_conv3x3_with_batchnorm_statistics(case):
     assert_close(got[1].cpu(), 1.0 / torch.sqrt(flat.var(1, unbiased=False) + 1e-5), 2e-6, "invstd against torch")
 
 
-@pytest.mark.parametrize("cout", [64, 32])
-def test_conv3x3_operands_beyond_fp16_range_stay_finite(cout):
-    """Activations of 3e5 and 1e7 (an untrained network's samples reach such values late in a 1000-step loop): every
-    arithmetic gives finite outputs; the fp16 pair clips such operands to +-65536 (fp16 conversions saturate), so its
-    result is the convolution of the clipped input, and pixels out of the large values' reach are what they are
-    without them. Halo kernel (64 output channels) and generic kernel (32)."""
-    from diffusion_model_amd._lib import conv_math
-    B, ci, H, W = 2, 32, 12, 12
-    x, w = rnd((B, ci, H, W), 31), rnd((cout, ci, 3, 3), 32, 0.1)
-    big = x.clone()
-    big[0, 5, 3, 3], big[0, 7, 3, 4], big[1, 0, 8, 8] = 3.0e5, -1.0e7, 7.0e4
-    wp = torch.empty(packed_floats(9, cout, ci), device="cuda")
-    call("ddpm_pack_conv3x3", P(w.cuda().contiguous()), cout, ci, 0, P(wp), stream())
-    d = ConvDesc(batch=B, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=cout, ldo=cout, act=0, ldr=0, out_h=H, out_w=W)
-    ep = Epilogue(None, None, None, None)
-    out = torch.empty((B, H, W, cout), device="cuda")
-    call("ddpm_conv3x3_fwd", C.byref(d), P(to_nhwc(big)), None, P(wp), C.byref(ep), P(out), stream())
-    got = from_nhwc(out)
-    assert torch.isfinite(got).all()
-    seen = big.clamp(-65536.0, 65536.0) if conv_math() == "f16x2" else big
-    want = F.conv2d(seen.double(), w.double(), padding=1)
-    assert_close(got, want, TOL, f"conv3x3 with operands beyond fp16's range ({conv_math()})")
-    clean = F.conv2d(x.double(), w.double(), padding=1)
-    far = torch.ones(B, 1, H, W, dtype=torch.bool)
-    far[0, :, 2:5, 2:6] = False
-    far[1, :, 7:10, 7:10] = False
-    assert ((got.double() - clean).abs() * far).max().item() <= 2e-5 * clean.abs().max().item()
-
-
 def test_conv3x3_two_sources_and_strided_output():
     """Input = channel concat of two tensors with their own pixel strides; output into a wider buffer."""
     B, H, W, c1, c2, co = 2, 12, 10, 24, 40, 48

@@ -72,9 +72,37 @@ def test_label_outside_the_embedding_table_raises(bad):
             m(x, t, torch.tensor([bad]).cuda())
         ok = m(x, t, torch.tensor([3, 9]).cuda())          # the largest valid label still works afterwards
     assert torch.isfinite(ok).all()
+    # a training step does not wait for the device: the bad sample's prediction is NaN (the kernels never dereference
+    # the label) and the error is raised by the next call that finds the verdict arrived
     m.train()
+    out = m(x, t, torch.tensor([bad, 0]).cuda())
+    assert torch.isnan(out[0]).all() and torch.isfinite(out[1]).all()
+    torch.cuda.synchronize()
     with pytest.raises(IndexError, match="label out of range"):
-        m(x, t, torch.tensor([bad, 0]).cuda())
+        m(x, t, torch.tensor([1, 0]).cuda())
+    assert torch.isfinite(m(x, t, torch.tensor([1, 0]).cuda())).all()     # reported once
+
+
+def test_training_step_with_fresh_labels_does_not_synchronise():
+    """A conditional training step (third-iteration/main.py:91 with labels) gets a new label tensor every iteration;
+    neither the forward nor the backward may make the host wait for the GPU."""
+    m, _ = _tiny_v3()
+    m.train()
+    x, t = seeded_tensor((4, 1, 28, 28), 1, "x").cuda(), torch.tensor([5, 900, 17, 0]).cuda()
+    tgt = seeded_tensor((4, 1, 28, 28), 2, "tgt").cuda()
+    labels = [torch.tensor(v).cuda() for v in ([1, 2, 3, 4], [9, 0, 5, 5], [7, 7, 1, 0])]
+    crit = torch.nn.MSELoss()
+    crit(m(x, t, labels[0]), tgt).backward()                # first step: caches, workspaces, pinned buffers
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for y in labels[1:]:
+            m.zero_grad()
+            crit(m(x, t, y), tgt).backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
 
 
 def test_label_kernels_never_dereference_a_bad_label():
