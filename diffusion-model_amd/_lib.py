@@ -29,7 +29,7 @@ class EmbedBwdArgs(C.Structure):
 
 
 class EmbedArgs(C.Structure):
-    _fields_ = [("batch", I32), ("emb_dim", I32), ("n_labels", I32), ("t_is_float", I32), ("n_classes", I32), ("reserved", I32),
+    _fields_ = [("batch", I32), ("emb_dim", I32), ("n_labels", I32), ("t_is_float", I32), ("n_classes", I32), ("uniform", I32),
                 ("t", P), ("y", P), ("label_table", P),
                 ("ch", I32 * 4), ("w", P * 4), ("b", P * 4), ("lw", P * 4), ("lb", P * 4),
                 ("out", P * 4), ("emb_out", P)]

@@ -983,21 +983,18 @@ int launch_x3p_math(const AttnParams& p, int batch, hipStream_t s) {
     return ddpm::check_launch("attention_fwd_x3p_kernel");
 }
 
-// Which calls take the fp16 pair (when it is the process's arithmetic):
-//  * inference calls only (no log-sum-exp requested). A training forward hands its log-sum-exp to the backward
-//    kernels, which recompute the probabilities in the three-plane bf16 arithmetic: scores rounded differently on the
-//    two sides would leave the recomputed rows slightly unnormalised, and the ill-conditioned gradients of the
-//    attention block (query/key weights, gamma) are where that shows (measured on the full-size training step: 3.5
-//    instead of 1-2 times the fp32 CPU reference's own distance from float64). Forward and backward stay on one
-//    arithmetic.
-//  * at most 16 query channels: the pair needs a second set of output accumulators, and with 32 query channels (two
-//    depth chunks of Q and K fragments besides) that no longer fits the register file at two waves per SIMD; that
-//    shape (256 channels, maps of 16 x 16 and smaller) is short anyway.
+// Which calls take the fp16 pair (when it is the process's arithmetic): those with at most 16 query channels. The pair
+// needs a second set of output accumulators, and with 32 query channels (two depth chunks of Q and K fragments besides)
+// that no longer fits the register file at two waves per SIMD; that shape (256 channels, maps of 16 x 16 and smaller) is
+// short anyway. Training calls (a log-sum-exp is requested) take it too: the backward kernels of these shapes recompute
+// the probabilities from that log-sum-exp in the same arithmetic (attention_bwd.hip), so that scores are rounded the same
+// way on both sides. DDPM_ATTN_TRAIN_F16=0 (read once, by both files) keeps training calls on three bf16 planes:
+// a diagnostic switch for A/B measurements.
 template <int DQ>
 bool fp16_pair_call(const AttnParams& p) {
-    static const bool train_too = [] {   // DDPM_ATTN_TRAIN_F16=1: diagnostic switch, the pair for training calls as well
+    static const bool train_too = [] {
         const char* e = getenv("DDPM_ATTN_TRAIN_F16");
-        return e && strcmp(e, "1") == 0;
+        return !(e && strcmp(e, "0") == 0);
     }();
     return DQ <= 16 && ddpm::f16_math() && (p.lse == nullptr || train_too);
 }

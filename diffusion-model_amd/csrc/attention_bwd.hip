@@ -13,6 +13,7 @@
 // in the transposed orientation. The x-gradient pass-through (dx += dY) is the caller's.
 #include "attention_small.h"
 #include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -32,6 +33,7 @@ struct BwdParams {
     const float* gamma;
     float* dqkv;         // [B][N][lq]
     int n, c, dqp, lq, ldd;
+    unsigned* range_flag;   // fp16-pair kernels: raised when an operand lies beyond fp16's range
 };
 
 // E[b][i] = dY[i].O[i]; partial sums of E per workgroup for dgamma. A row takes c / 4 lanes (16 bytes each) up to a
@@ -645,20 +647,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_fast_kernel(const BwdParam
 }
 
 
-// ---- split-bf16 variants of the fast paths -------------------------------------------------------
-// Same mathematics and wave ownership as the fast kernels above, on v_mfma_f32_32x32x16_bf16: every
-// fp32 operand is the exact sum of three bf16 numbers (hi + mid + lo) and a product is evaluated as
-// its six cross terms of weight >= 2^-16 with fp32 accumulation (dropped terms below 2^-23 of the
-// product). Tiles that stream past are split on their way to LDS (three bf16 planes); the wave's
-// fixed operand is split once into registers; P and dS are split in registers and, being in the
-// accumulator layout (lane = column, register = row), serve as B operands as they stand. The
-// operands that the fp32 kernels fetched with one 4-byte LDS read per MFMA (dO^T, Q^T, K^T) come from
+// ---- split-operand variants of the fast paths -----------------------------------------------------
+// Same mathematics and wave ownership as the fast kernels above, on the 16-bit matrix instructions. Tiles that
+// stream past are split on their way to LDS; the wave's fixed operand is split once into registers; P and dS are
+// split in registers and, being in the accumulator layout (lane = column, register = row), serve as B operands as
+// they stand. The operands that the fp32 kernels fetched with one 4-byte LDS read per MFMA (dO^T, Q^T, K^T) come from
 // the transposing read ds_read_b64_tr_b16, in the key/query order the score registers hold.
+//  * three bf16 planes (F16 = false): every fp32 operand is the exact sum of three bf16 numbers (hi + mid + lo) and a
+//    product is evaluated as its six cross terms of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16 with fp32
+//    accumulation (dropped terms below 2^-23 of the product);
+//  * fp16 pair (F16 = true; conv_common.h): hi and the remainder scaled by 2^11, three products per fragment pair on
+//    v_mfma_f32_32x32x16_f16 -- hi*hi into a main accumulator, the two cross products into a second one that is
+//    scaled by 2^-11 and added when the sum is complete. The forward pass of a training call runs in the same
+//    arithmetic (attention.hip), so that the probabilities recomputed here from its log-sum-exp are the ones it used.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+using ddpm::conv::kLoInv;
+using ddpm::conv::mfma16;
 
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
     unsigned u[8], m[8], l[8];
@@ -700,8 +708,32 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst, 
     *reinterpret_cast<u32x2*>(dst + 2 * plane_stride) = lo;
 }
 
-// 8 floats at p (two float4; zeros when !ok) -> three planes
-__device__ __forceinline__ void load_split8(const float* p, bool ok, u32x4& hi, u32x4& mid, u32x4& lo, float scale) {
+// The same for the fp16 pair: two planes; `amax` is the thread's range watch (conv_common.h).
+__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, float& amax) {
+    unsigned hh[4], ll[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const ddpm::conv::f32x2 x = {v[2 * e], v[2 * e + 1]};
+        ddpm::conv::watch2(amax, x);
+        ddpm::conv::split2_pair(x, hh[e], ll[e]);
+    }
+    hi = u32x4{hh[0], hh[1], hh[2], hh[3]};
+    lo = u32x4{ll[0], ll[1], ll[2], ll[3]};
+}
+
+__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, int plane_stride, float& amax) {
+    unsigned h0, l0, h1, l1;
+    ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[0], v[1]});
+    ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[2], v[3]});
+    ddpm::conv::split2_pair(ddpm::conv::f32x2{v[0], v[1]}, h0, l0);
+    ddpm::conv::split2_pair(ddpm::conv::f32x2{v[2], v[3]}, h1, l1);
+    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(dst + plane_stride) = u32x2{l0, l1};
+}
+
+// 8 floats at p (two float4; zeros when !ok), times `scale` -> the operand's planes (pl[2] unused by the fp16 pair)
+template <bool F16>
+__device__ __forceinline__ void load_split8(const float* p, bool ok, u32x4 (&pl)[F16 ? 2 : 3], float scale, float& amax) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -713,14 +745,43 @@ __device__ __forceinline__ void load_split8(const float* p, bool ok, u32x4& hi, 
             v[4 + j] = b[j] * scale;
         }
     }
-    split8(v, hi, mid, lo);
+    if constexpr (F16) split8_f16(v, pl[0], pl[1], amax);
+    else split8(v, pl[0], pl[1], pl[2]);
 }
 
-__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* a0, const unsigned char* a1) {
+template <bool F16>
+__device__ __forceinline__ void split8_any(const float (&v)[8], u32x4 (&pl)[F16 ? 2 : 3], float& amax) {
+    if constexpr (F16) split8_f16(v, pl[0], pl[1], amax);
+    else split8(v, pl[0], pl[1], pl[2]);
+}
+
+template <bool F16>
+__device__ __forceinline__ void split4_store_any(const f32x4 v, unsigned char* dst, int plane_stride, float& amax) {
+    if constexpr (F16) split4_store_f16(v, dst, plane_stride, amax);
+    else split4_store(v, dst, plane_stride);
+}
+
+__device__ __forceinline__ u32x4 tr_pair(const unsigned char* a0, const unsigned char* a1) {
     const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
     const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+    return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+
+// The products of one fragment pair, in issue order: plane of the A operand, plane of the B operand, and (fp16 pair)
+// whether the product is a cross term, which goes to the cross accumulator.
+template <bool F16>
+struct Products {
+    static constexpr int N = F16 ? 3 : 6;
+    __host__ __device__ static constexpr int pa(int k) {
+        constexpr int t[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0};
+        return t[k];
+    }
+    __host__ __device__ static constexpr int pb(int k) {
+        constexpr int t[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
+        return t[k];
+    }
+    __host__ __device__ static constexpr bool cross(int k) { return F16 && k < 2; }
+};
 
 // 256-byte rows of 16-bit elements read both row-wise (ds_read_b128) and transposed (ds_read_b64_tr_b16):
 // 16-byte chunk ch of row `row` lives at this offset; both kinds of read are then bank-conflict-free.
@@ -731,10 +792,14 @@ __device__ __forceinline__ int swz(int row, int ch) { return 256 * row + 16 * (c
 // starting at bid.y * CT (CT <= 128; the dO tile is read transposed and sits in swizzled 256-byte
 // rows). Both at once when the registers allow (C <= 128); wider layers run the two halves as separate
 // launches, each recomputing the scores (depth-DQ products, cheap beside the C-deep ones).
-template <int DQ, int CT, bool DK, bool DV, int WPS = 1>
+template <int DQ, int CT, bool DK, bool DV, int WPS = 1, bool F16 = false>
 __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdParams p) {
+    if constexpr (F16) ddpm::conv::fp16_saturate();
+    float amax = 0.f;                     // F16: largest magnitude this thread has turned into an fp16 pair
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     static_assert(!DV || CT <= 128, "transposed dO reads assume 256-byte rows");
+    using PR = Products<F16>;
+    constexpr int NPL = F16 ? 2 : 3;
     constexpr int NCT = CT / 32, KCV = CT / 16;
     constexpr int KD = DQ < 16 ? 16 : DQ, KQ = KD / 16;   // padded depth, 16-deep chunks of it
     constexpr int QROW = 2 * KD, QPLANE = 32 * QROW;      // bytes
@@ -742,9 +807,9 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
     constexpr int DOPT = TQ * CT / 4 / 256;               // dO float4 per thread
     constexpr int QF4 = TQ * DQ / 4;                      // Q float4 per tile (<= 256)
     extern __shared__ __attribute__((aligned(256))) unsigned char dyn_lds[];
-    unsigned char* sDO = dyn_lds;                          // [2][3 * DPLANE]
-    unsigned char* sQ = sDO + 2 * 3 * DPLANE;              // [2][3 * QPLANE]
-    float* sL = reinterpret_cast<float*>(sQ + 2 * 3 * QPLANE);   // [2][TQ]
+    unsigned char* sDO = dyn_lds;                          // [2][NPL * DPLANE]
+    unsigned char* sQ = sDO + 2 * NPL * DPLANE;            // [2][NPL * QPLANE]
+    float* sL = reinterpret_cast<float*>(sQ + 2 * NPL * QPLANE);   // [2][TQ]
     float* sD = sL + 2 * TQ;                               // [2][TQ]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -763,36 +828,38 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
     const float* eb = p.e + static_cast<int64_t>(b) * p.n;
 
     if (DQ < 16) {   // the upper half of the padded depth of the Q tile stays zero
-        for (int i = tid; i < 2 * 3 * QPLANE / 4; i += 256) reinterpret_cast<unsigned*>(sQ)[i] = 0u;
+        for (int i = tid; i < 2 * NPL * QPLANE / 4; i += 256) reinterpret_cast<unsigned*>(sQ)[i] = 0u;
     }
 
     // fixed operands of this wave's 32 keys: lane (key, h) holds depth / channels 16*chunk + 8h .. + 7
-    u32x4 kf[KQ][3], vf[DK ? KCV : 1][3];
+    u32x4 kf[KQ][NPL], vf[DK ? KCV : 1][NPL];
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq)
-        load_split8(base + static_cast<int64_t>(kj) * p.lq + DQ + 16 * kq + 8 * h, k_ok && 16 * kq + 8 * h < DQ, kf[kq][0], kf[kq][1],
-                    kf[kq][2], 1.0f);
+        load_split8<F16>(base + static_cast<int64_t>(kj) * p.lq + DQ + 16 * kq + 8 * h, k_ok && 16 * kq + 8 * h < DQ, kf[kq], 1.0f, amax);
     if (DK) {
 #pragma unroll
         for (int kc = 0; kc < KCV; ++kc)
-            load_split8(base + static_cast<int64_t>(kj) * p.lq + 2 * DQ + 16 * kc + 8 * h, k_ok, vf[kc][0], vf[kc][1], vf[kc][2], 1.0f);
+            load_split8<F16>(base + static_cast<int64_t>(kj) * p.lq + 2 * DQ + 16 * kc + 8 * h, k_ok, vf[kc], 1.0f, amax);
     }
 
     // An MFMA that accumulates into the registers the previous one wrote waits for it (a chain of dependent
-    // v_mfma_f32_32x32x16_bf16 runs at half the rate of two interleaved chains), so every product below alternates
-    // between two accumulators: dK keeps one per 16-query chunk and adds them at the end, the scores and dP keep two
-    // partial sums per tile, dV takes its channel blocks in pairs.
-    f32x16 dv[DV ? NCT : 1], dk2[2];
+    // 32x32x16 MFMAs runs at half the rate of two interleaved chains), so every product below rotates over two or
+    // three accumulators. bf16 planes: dK keeps one per 16-query chunk and adds them at the end, the scores and dP keep
+    // two partial sums per tile, dV takes its channel blocks in pairs. fp16 pair: main and cross accumulators alternate
+    // by themselves; where two chunks run side by side each has its own cross accumulator.
+    f32x16 dv[DV ? NCT : 1], dvx[(DV && F16) ? NCT : 1], dk2[2];   // fp16 pair: dk2[0] main, dk2[1] cross products
 #pragma unroll
     for (int t = 0; t < (DV ? NCT : 1); ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dv[t][e] = 0.f;
+        for (int e = 0; e < 16; ++e) {
+            dv[t][e] = 0.f;
+            if constexpr (DV && F16) dvx[t][e] = 0.f;
+        }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         dk2[0][e] = 0.f;
         dk2[1][e] = 0.f;
     }
-    constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
 
     auto dofs = [](int row, int ch) { return DV ? swz(row, ch) : row * DROW + 16 * ch; };
 
@@ -825,11 +892,11 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
         for (int i = 0; i < DOPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CT / 4), c4 = f % (CT / 4);
-            split4_store(doreg[i] * g, sDO + buf * 3 * DPLANE + dofs(row, c4 >> 1) + 8 * (c4 & 1), DPLANE);
+            split4_store_any<F16>(doreg[i] * g, sDO + buf * NPL * DPLANE + dofs(row, c4 >> 1) + 8 * (c4 & 1), DPLANE, amax);
         }
         if (tid < QF4) {
             const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
-            split4_store(qreg, sQ + buf * 3 * QPLANE + row * QROW + c4 * 8, QPLANE);
+            split4_store_any<F16>(qreg, sQ + buf * NPL * QPLANE + row * QROW + c4 * 8, QPLANE, amax);
         }
         if (tid < TQ) {
             sL[buf * TQ + tid] = lreg;
@@ -845,6 +912,7 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
     // Q tile: QROW-byte rows of KD depth values; with KD = 16 the second column group (depth rows >= 16) is never stored
     const int qtr = (4 * h + tq) * QROW + tp * 8 + (KD > 16 ? tg * 32 : 0);
 
+    float amax_ds = 0.f;   // largest |dS| split by this lane; counts only if the lane's key exists
     const int qtiles = (p.n + TQ - 1) / TQ;
     load_tile(0);
     __syncthreads();
@@ -855,54 +923,70 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
         const bool more = t + 1 < qtiles;
         if (more) load_tile(i0 + TQ);
         if (wave_active) {
-            const unsigned char* q = sQ + buf * 3 * QPLANE;
-            const unsigned char* dO = sDO + buf * 3 * DPLANE;
-            f32x16 s, s1, dp, dp1;
+            const unsigned char* q = sQ + buf * NPL * QPLANE;
+            const unsigned char* dO = sDO + buf * NPL * DPLANE;
+            // bf16 planes: s + s1 and dp + dp1 are two partial sums each; fp16 pair: s1 and dp1 hold the cross
+            // products (scaled and added below), dp2 the cross products of the second chunk of a pair
+            f32x16 s, s1, dp, dp1, dp2;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 s[e] = 0.f;
                 s1[e] = 0.f;
                 dp[e] = 0.f;
                 dp1[e] = 0.f;
+                if constexpr (F16) dp2[e] = 0.f;
             }
-            auto mma = [&](f32x16& acc, const bf16x8& a, const u32x4& bb) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bb), acc, 0, 0, 0);
-            };
+            auto mma = [&](f32x16& acc, const u32x4& a, const u32x4& bb) { acc = mfma16<F16>(a, bb, acc); };
             // S = Q K^T: rows = queries (this tile), columns = keys (lanes)
-            bf16x8 aq[KQ][3];
+            u32x4 aq[KQ][NPL];
 #pragma unroll
             for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) aq[kq][pl] = *reinterpret_cast<const bf16x8*>(q + pl * QPLANE + r * QROW + kq * 32 + h * 16);
-            if (DK) {
-                // dP = dO V^T, two 16-channel chunks at a time into two partial sums; the MFMAs of the scores (one chain)
-                // go between the first of them
-                static_assert(!DK || (KCV % 2 == 0 && KQ <= KCV / 2), "chunk pairs; the scores fit between them");
-#pragma unroll
-                for (int kc = 0; kc < KCV; kc += 2) {
-                    bf16x8 a[2][3];
-#pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
-                            a[c2][pl] = *reinterpret_cast<const bf16x8*>(dO + pl * DPLANE + r * DROW + 16 * ((2 * (kc + c2) + h) ^ sw_row));
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        if (kc / 2 < KQ) mma(s, aq[kc / 2 < KQ ? kc / 2 : 0][pa[k]], kf[kc / 2 < KQ ? kc / 2 : 0][pb[k]]);
-                        mma(dp, a[0][pa[k]], vf[kc][pb[k]]);
-                        mma(dp1, a[1][pa[k]], vf[kc + 1][pb[k]]);
-                    }
-                }
-                dp += dp1;
-            } else {
+                for (int pl = 0; pl < NPL; ++pl) aq[kq][pl] = *reinterpret_cast<const u32x4*>(q + pl * QPLANE + r * QROW + kq * 32 + h * 16);
+            if constexpr (F16) {
+                // (the pair's scores are three products per depth chunk: they go first, so that their cross accumulator
+                // is free again before the accumulators of dP are taken)
 #pragma unroll
                 for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) mma((k & 1) ? s1 : s, aq[kq][pa[k]], kf[kq][pb[k]]);
+                    for (int k = 0; k < PR::N; ++k) mma(PR::cross(k) ? s1 : s, aq[kq][PR::pa(k)], kf[kq][PR::pb(k)]);
+                s = s + s1 * kLoInv;
+            }
+            if (DK) {
+                // dP = dO V^T, two 16-channel chunks at a time; (bf16 planes) the MFMAs of the scores go between the first of them
+                static_assert(!DK || (KCV % 2 == 0 && KQ <= KCV / 2), "chunk pairs; the scores fit between them");
+#pragma unroll
+                for (int kc = 0; kc < KCV; kc += 2) {
+                    u32x4 a[2][NPL];
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl)
+                            a[c2][pl] = *reinterpret_cast<const u32x4*>(dO + pl * DPLANE + r * DROW + 16 * ((2 * (kc + c2) + h) ^ sw_row));
+#pragma unroll
+                    for (int k = 0; k < PR::N; ++k) {
+                        const bool x = PR::cross(k);
+                        if (!F16 && kc / 2 < KQ) mma(s, aq[kc / 2 < KQ ? kc / 2 : 0][PR::pa(k)], kf[kc / 2 < KQ ? kc / 2 : 0][PR::pb(k)]);
+                        if constexpr (F16) {
+                            mma(x ? dp1 : dp, a[0][PR::pa(k)], vf[kc][PR::pb(k)]);
+                            mma(x ? dp2 : dp, a[1][PR::pa(k)], vf[kc + 1][PR::pb(k)]);
+                        } else {
+                            mma(dp, a[0][PR::pa(k)], vf[kc][PR::pb(k)]);
+                            mma(dp1, a[1][PR::pa(k)], vf[kc + 1][PR::pb(k)]);
+                        }
+                    }
+                }
+                if constexpr (F16) dp = dp + (dp1 + dp2) * kLoInv;
+                else dp += dp1;
+            } else if constexpr (!F16) {
+#pragma unroll
+                for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+                    for (int k = 0; k < PR::N; ++k) mma((k & 1) ? s1 : s, aq[kq][PR::pa(k)], kf[kq][PR::pb(k)]);
                 s += s1;
             }
             // P and dS, split into planes per 16-query chunk (register e <-> query rowmap(e, h))
-            u32x4 pp[2][3], ds[2][3];
+            u32x4 pp[2][NPL], ds[2][NPL];
 #pragma unroll
             for (int ck = 0; ck < 2; ++ck) {
                 float pv[8], dsv[8];
@@ -922,8 +1006,11 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
                         dsv[4 * g4 + e4] = pe * (dp[e] - d4[e4]);
                     }
                 }
-                if (DV) split8(pv, pp[ck][0], pp[ck][1], pp[ck][2]);
-                if (DK) split8(dsv, ds[ck][0], ds[ck][1], ds[ck][2]);
+                // (range watch: probabilities are at most 1 on real keys and need none; a key past the end holds
+                // exp(-lse), possibly infinite, in a column that is never stored, and must not raise the flag either)
+                float unwatched = 0.f;
+                if (DV) split8_any<F16>(pv, pp[ck], unwatched);
+                if (DK) split8_any<F16>(dsv, ds[ck], amax_ds);
             }
             if (DV) {
                 // dV^T += dO^T P : A = dO^T through transposed reads (rows = channels of block ct, k = queries)
@@ -932,38 +1019,53 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
                 for (int ck = 0; ck < 2; ++ck) {
 #pragma unroll
                     for (int ct = 0; ct < NCT; ct += 2) {
-                        bf16x8 a[2][3];
+                        u32x4 a[2][NPL];
                         const int row0 = 16 * ck + 4 * h + tq;
 #pragma unroll
                         for (int c2 = 0; c2 < 2; ++c2) {
                             const int ch0 = 4 * (ct + c2) + 2 * tg + (tp >> 1);
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) {
+                            for (int pl = 0; pl < NPL; ++pl) {
                                 const unsigned char* pbase = dO + pl * DPLANE + 8 * (tp & 1);
                                 a[c2][pl] = tr_pair(pbase + 256 * row0 + 16 * (ch0 ^ tsw0), pbase + 256 * (row0 + 8) + 16 * (ch0 ^ tsw1));
                             }
                         }
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) {
-                            mma(dv[ct], a[0][pa[k]], pp[ck][pb[k]]);
-                            mma(dv[ct + 1], a[1][pa[k]], pp[ck][pb[k]]);
+                        for (int k = 0; k < PR::N; ++k) {
+                            if (PR::cross(k)) {
+                                mma(dvx[F16 ? ct : 0], a[0][PR::pa(k)], pp[ck][PR::pb(k)]);
+                                mma(dvx[F16 ? ct + 1 : 0], a[1][PR::pa(k)], pp[ck][PR::pb(k)]);
+                            } else {
+                                mma(dv[ct], a[0][PR::pa(k)], pp[ck][PR::pb(k)]);
+                                mma(dv[ct + 1], a[1][PR::pa(k)], pp[ck][PR::pb(k)]);
+                            }
                         }
                     }
                 }
             }
             if (DK) {   // dK^T += Q^T dS, the two 16-query chunks side by side
-                bf16x8 a[2][3];
+                u32x4 a[2][NPL];
 #pragma unroll
                 for (int ck = 0; ck < 2; ++ck)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
+                    for (int pl = 0; pl < NPL; ++pl) {
                         const unsigned char* pbase = q + pl * QPLANE + 16 * ck * QROW + qtr;
                         a[ck][pl] = tr_pair(pbase, pbase + 8 * QROW);
                     }
+                if constexpr (F16) {
+                    // six products, main and cross accumulator as far as possible in turn
+                    mma(dk2[1], a[0][1], ds[0][0]);
+                    mma(dk2[0], a[0][0], ds[0][0]);
+                    mma(dk2[1], a[0][0], ds[0][1]);
+                    mma(dk2[0], a[1][0], ds[1][0]);
+                    mma(dk2[1], a[1][1], ds[1][0]);
+                    mma(dk2[1], a[1][0], ds[1][1]);
+                } else {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    mma(dk2[0], a[0][pa[k]], ds[0][pb[k]]);
-                    mma(dk2[1], a[1][pa[k]], ds[1][pb[k]]);
+                    for (int k = 0; k < PR::N; ++k) {
+                        mma(dk2[0], a[0][PR::pa(k)], ds[0][PR::pb(k)]);
+                        mma(dk2[1], a[1][PR::pa(k)], ds[1][PR::pb(k)]);
+                    }
                 }
             }
         }
@@ -971,20 +1073,23 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
         __syncthreads();
     }
 
+    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, k_ok ? __builtin_fmaxf(amax, amax_ds) : amax);
     if (!wave_active || !k_ok) return;
     float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + kj) * p.lq;
     if (DV) {
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+        for (int ct = 0; ct < NCT; ++ct) {
+            if constexpr (F16) dv[ct] = dv[ct] + dvx[ct] * kLoInv;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int ch = c0 + ct * 32 + gq * 8 + h * 4;
                 f32x4 v = {dv[ct][gq * 4], dv[ct][gq * 4 + 1], dv[ct][gq * 4 + 2], dv[ct][gq * 4 + 3]};
                 *reinterpret_cast<f32x4*>(drow + 2 * DQ + ch) = v;
             }
+        }
     }
     if (DK) {
-        const f32x16 dk = dk2[0] + dk2[1];
+        const f32x16 dk = F16 ? dk2[0] + dk2[1] * kLoInv : dk2[0] + dk2[1];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int d = gq * 8 + h * 4;
@@ -995,16 +1100,20 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
     }
 }
 
-template <int DQ, int CT, bool DK, bool DV>
+template <int DQ, int CT, bool DK, bool DV, bool F16 = false>
 constexpr int dkv_x3_lds() {
-    constexpr int KD = DQ < 16 ? 16 : DQ;
-    return 2 * 3 * 32 * (DV ? 256 : CT * 2 + 16) + 2 * 3 * 32 * 2 * KD + 4 * TQ * 4;
+    constexpr int KD = DQ < 16 ? 16 : DQ, NPL = F16 ? 2 : 3;
+    return 2 * NPL * 32 * (DV ? 256 : CT * 2 + 16) + 2 * NPL * 32 * 2 * KD + 4 * TQ * 4;
 }
 
 // Query-side gradient of 32 queries per wave (dO of all CT = C channels in registers).
-template <int DQ, int CT>
+template <int DQ, int CT, bool F16 = false>
 __global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(const BwdParams p) {
+    if constexpr (F16) ddpm::conv::fp16_saturate();
+    float amax = 0.f;                     // F16: largest magnitude this thread has turned into an fp16 pair
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
+    using PR = Products<F16>;
+    constexpr int NPL = F16 ? 2 : 3;
     constexpr int KCV = CT / 16;
     constexpr int KD = DQ < 16 ? 16 : DQ, KQ = KD / 16;
     constexpr int KROW = 2 * KD, KPLANE = 32 * KROW;
@@ -1013,8 +1122,8 @@ __global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(
     constexpr int VPT = 32 * CT / 4 / 256;
     constexpr int KF4 = 32 * DQ / 4;
     extern __shared__ __attribute__((aligned(256))) unsigned char dyn_lds[];
-    unsigned char* sV = dyn_lds;                  // [2][3 * VPLANE]
-    unsigned char* sK = sV + 2 * 3 * VPLANE;      // [2][3 * KPLANE]
+    unsigned char* sV = dyn_lds;                    // [2][NPL * VPLANE]
+    unsigned char* sK = sV + 2 * NPL * VPLANE;      // [2][NPL * KPLANE]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1028,29 +1137,27 @@ __global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(
     const float* base = p.qkv + static_cast<int64_t>(b) * p.n * p.lq;
 
     if (DQ < 16) {
-        for (int i = tid; i < 2 * 3 * KPLANE / 4; i += 256) reinterpret_cast<unsigned*>(sK)[i] = 0u;
+        for (int i = tid; i < 2 * NPL * KPLANE / 4; i += 256) reinterpret_cast<unsigned*>(sK)[i] = 0u;
     }
 
     // fixed operands of this wave's 32 queries: lane (query, h) holds depth / channels 16*chunk + 8h .. + 7
-    u32x4 qf[KQ][3], dof[KCV][3];
+    u32x4 qf[KQ][NPL], dof[KCV][NPL];
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq)
-        load_split8(base + static_cast<int64_t>(qi) * p.lq + 16 * kq + 8 * h, q_ok && 16 * kq + 8 * h < DQ, qf[kq][0], qf[kq][1], qf[kq][2],
-                    1.0f);
+        load_split8<F16>(base + static_cast<int64_t>(qi) * p.lq + 16 * kq + 8 * h, q_ok && 16 * kq + 8 * h < DQ, qf[kq], 1.0f, amax);
 #pragma unroll
     for (int kc = 0; kc < KCV; ++kc)
-        load_split8(p.dy + (static_cast<int64_t>(b) * p.n + qi) * p.ldd + 16 * kc + 8 * h, q_ok, dof[kc][0], dof[kc][1], dof[kc][2], g);
+        load_split8<F16>(p.dy + (static_cast<int64_t>(b) * p.n + qi) * p.ldd + 16 * kc + 8 * h, q_ok, dof[kc], g, amax);
     const float lse_i = q_ok ? p.lse[static_cast<int64_t>(b) * p.n + qi] : 0.f;
     const float d_i = q_ok ? g * p.e[static_cast<int64_t>(b) * p.n + qi] : 0.f;
 
-    // (two accumulators per product, taken in turn: see the key-side kernel)
+    // (accumulators taken in turn: see the key-side kernel; fp16 pair: dq2[0] main, dq2[1] cross products)
     f32x16 dq2[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         dq2[0][e] = 0.f;
         dq2[1][e] = 0.f;
     }
-    constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
 
     // K and V rows through a range-checked descriptor over the sample's [n][lq] block: no branch around the loads
     const __amdgpu_buffer_rsrc_t rs_kv = ddpm::buffer_over(base, static_cast<long long>(p.n) * p.lq * 4ll);
@@ -1070,13 +1177,13 @@ __global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(
     auto store_tile = [&](int buf) {
         if (tid < KF4) {
             const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
-            split4_store(kreg, sK + buf * 3 * KPLANE + row * KROW + c4 * 8, KPLANE);
+            split4_store_any<F16>(kreg, sK + buf * NPL * KPLANE + row * KROW + c4 * 8, KPLANE, amax);
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CT / 4), c4 = f % (CT / 4);
-            split4_store(vreg[i], sV + buf * 3 * VPLANE + row * VROW + c4 * 8, VPLANE);
+            split4_store_any<F16>(vreg[i], sV + buf * NPL * VPLANE + row * VROW + c4 * 8, VPLANE, amax);
         }
     };
 
@@ -1094,43 +1201,59 @@ __global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(
         const bool more = t + 1 < ktiles;
         if (more) load_tile(j0 + 32);
         if (wave_active) {
-            const unsigned char* k = sK + buf * 3 * KPLANE;
-            const unsigned char* v = sV + buf * 3 * VPLANE;
-            f32x16 s, dp, dp1;
+            const unsigned char* k = sK + buf * NPL * KPLANE;
+            const unsigned char* v = sV + buf * NPL * VPLANE;
+            // fp16 pair: sx, dp1 and dp2 hold cross products (dp2: those of the second chunk of a pair)
+            f32x16 s, sx, dp, dp1, dp2;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 s[e] = 0.f;
                 dp[e] = 0.f;
                 dp1[e] = 0.f;
+                if constexpr (F16) {
+                    sx[e] = 0.f;
+                    dp2[e] = 0.f;
+                }
             }
-            auto mma = [&](f32x16& acc, const bf16x8& a, const u32x4& bb) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bb), acc, 0, 0, 0);
-            };
+            auto mma = [&](f32x16& acc, const u32x4& a, const u32x4& bb) { acc = mfma16<F16>(a, bb, acc); };
             // S^T = K Q^T: rows = keys (this tile), columns = queries (lanes)
-            bf16x8 ak[KQ][3];
+            u32x4 ak[KQ][NPL];
 #pragma unroll
             for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) ak[kq][pl] = *reinterpret_cast<const bf16x8*>(k + pl * KPLANE + r * KROW + kq * 32 + h * 16);
-            // dP^T = V dO^T, two 16-channel chunks at a time into two partial sums; the MFMAs of the scores (one chain) go
-            // between the first of them
+                for (int pl = 0; pl < NPL; ++pl) ak[kq][pl] = *reinterpret_cast<const u32x4*>(k + pl * KPLANE + r * KROW + kq * 32 + h * 16);
+            if constexpr (F16) {   // (the pair's scores first: see the key-side kernel)
+#pragma unroll
+                for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+                    for (int kk = 0; kk < PR::N; ++kk) mma(PR::cross(kk) ? sx : s, ak[kq][PR::pa(kk)], qf[kq][PR::pb(kk)]);
+                s = s + sx * kLoInv;
+            }
+            // dP^T = V dO^T, two 16-channel chunks at a time; (bf16 planes) the MFMAs of the scores go between the first of them
             static_assert(KCV % 2 == 0 && KQ <= KCV / 2, "chunk pairs; the scores fit between them");
 #pragma unroll
             for (int kc = 0; kc < KCV; kc += 2) {
-                bf16x8 a[2][3];
+                u32x4 a[2][NPL];
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[c2][pl] = *reinterpret_cast<const bf16x8*>(v + pl * VPLANE + r * VROW + (kc + c2) * 32 + h * 16);
+                    for (int pl = 0; pl < NPL; ++pl) a[c2][pl] = *reinterpret_cast<const u32x4*>(v + pl * VPLANE + r * VROW + (kc + c2) * 32 + h * 16);
 #pragma unroll
-                for (int kk = 0; kk < 6; ++kk) {
-                    if (kc / 2 < KQ) mma(s, ak[kc / 2 < KQ ? kc / 2 : 0][pa[kk]], qf[kc / 2 < KQ ? kc / 2 : 0][pb[kk]]);
-                    mma(dp, a[0][pa[kk]], dof[kc][pb[kk]]);
-                    mma(dp1, a[1][pa[kk]], dof[kc + 1][pb[kk]]);
+                for (int kk = 0; kk < PR::N; ++kk) {
+                    const bool x = PR::cross(kk);
+                    if (!F16 && kc / 2 < KQ) mma(s, ak[kc / 2 < KQ ? kc / 2 : 0][PR::pa(kk)], qf[kc / 2 < KQ ? kc / 2 : 0][PR::pb(kk)]);
+                    if constexpr (F16) {
+                        mma(x ? dp1 : dp, a[0][PR::pa(kk)], dof[kc][PR::pb(kk)]);
+                        mma(x ? dp2 : dp, a[1][PR::pa(kk)], dof[kc + 1][PR::pb(kk)]);
+                    } else {
+                        mma(dp, a[0][PR::pa(kk)], dof[kc][PR::pb(kk)]);
+                        mma(dp1, a[1][PR::pa(kk)], dof[kc + 1][PR::pb(kk)]);
+                    }
                 }
             }
-            dp += dp1;
-            u32x4 ds[2][3];
+            if constexpr (F16) dp = dp + (dp1 + dp2) * kLoInv;
+            else dp += dp1;
+            u32x4 ds[2][NPL];
 #pragma unroll
             for (int ck = 0; ck < 2; ++ck) {
                 // Only keys past the end need a mask (their rows of K^T meet dS in the product below; a probability that
@@ -1146,30 +1269,40 @@ __global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dsv[j] *= dp[8 * ck + j] - d_i;
-                split8(dsv, ds[ck][0], ds[ck][1], ds[ck][2]);
+                split8_any<F16>(dsv, ds[ck], amax);
             }
             {   // dQ^T += K^T dS^T, the two 16-key chunks side by side
-                bf16x8 a[2][3];
+                u32x4 a[2][NPL];
 #pragma unroll
                 for (int ck = 0; ck < 2; ++ck)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
+                    for (int pl = 0; pl < NPL; ++pl) {
                         const unsigned char* pbase = k + pl * KPLANE + 16 * ck * KROW + ktr;
                         a[ck][pl] = tr_pair(pbase, pbase + 8 * KROW);
                     }
+                if constexpr (F16) {
+                    mma(dq2[1], a[0][1], ds[0][0]);
+                    mma(dq2[0], a[0][0], ds[0][0]);
+                    mma(dq2[1], a[0][0], ds[0][1]);
+                    mma(dq2[0], a[1][0], ds[1][0]);
+                    mma(dq2[1], a[1][1], ds[1][0]);
+                    mma(dq2[1], a[1][0], ds[1][1]);
+                } else {
 #pragma unroll
-                for (int kk = 0; kk < 6; ++kk) {
-                    mma(dq2[0], a[0][pa[kk]], ds[0][pb[kk]]);
-                    mma(dq2[1], a[1][pa[kk]], ds[1][pb[kk]]);
+                    for (int kk = 0; kk < PR::N; ++kk) {
+                        mma(dq2[0], a[0][PR::pa(kk)], ds[0][PR::pb(kk)]);
+                        mma(dq2[1], a[1][PR::pa(kk)], ds[1][PR::pb(kk)]);
+                    }
                 }
             }
         }
         if (more) store_tile(buf ^ 1);
         __syncthreads();
     }
+    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, amax);
     if (!wave_active || !q_ok) return;
     float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + qi) * p.lq;
-    const f32x16 dq = dq2[0] + dq2[1];
+    const f32x16 dq = F16 ? dq2[0] + dq2[1] * kLoInv : dq2[0] + dq2[1];
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
         const int d = gq * 8 + h * 4;
@@ -1179,10 +1312,10 @@ __global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(
     }
 }
 
-template <int DQ, int CT>
+template <int DQ, int CT, bool F16 = false>
 constexpr int dq_x3_lds() {
-    constexpr int KD = DQ < 16 ? 16 : DQ;
-    return 2 * 3 * 32 * (CT * 2 + 16) + 2 * 3 * 32 * 2 * KD;
+    constexpr int KD = DQ < 16 ? 16 : DQ, NPL = F16 ? 2 : 3;
+    return 2 * NPL * 32 * (CT * 2 + 16) + 2 * NPL * 32 * 2 * KD;
 }
 
 template <typename K>
@@ -1190,37 +1323,53 @@ bool allow_lds(K kernel, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
 }
 
-// split-bf16 backward for the layers whose operands fit the register file: C <= 128 in two launches
-// (dK + dV, dQ), C = 256 in three (dK, dV per 128 channels, dQ).
-template <int DQ, int C>
-int launch_bwd_x3(const BwdParams& p, int batch, hipStream_t s) {
+// DDPM_ATTN_TRAIN_F16=0 (read once) keeps the attention of training calls (forward with a log-sum-exp, and this
+// backward) on three bf16 planes when the process computes with fp16 pairs: a diagnostic switch for A/B measurements.
+// attention.hip reads the same variable: the two sides always agree.
+inline bool pair_in_training() {
+    static const bool on = [] {
+        const char* e = getenv("DDPM_ATTN_TRAIN_F16");
+        return !(e && strcmp(e, "0") == 0);
+    }();
+    return on;
+}
+
+// split-operand backward for the layers whose operands fit the register file: C <= 128 in three launches
+// (dK, dV, dQ), C = 256 likewise (dV per 128 channels). The fp16 pair takes the layers whose forward takes it:
+// at most 16 query channels (C = 64 and 128).
+template <int DQ, int C, bool F16>
+int launch_bwd_x3_math(const BwdParams& p, int batch, hipStream_t s) {
     const int bn = (p.n + 127) / 128;
-#ifndef DDPM_ATTN_SPLIT128
-#define DDPM_ATTN_SPLIT128 1
-#endif
-    if constexpr (C <= 128 && !DDPM_ATTN_SPLIT128) {
-        constexpr int lds = dkv_x3_lds<DQ, C, true, true>();
-        if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, true>, lds)) return ddpm::fail_invalid("LDS size for attention backward (dkv)");
-        attn_bwd_dkv_x3_kernel<DQ, C, true, true><<<dim3(bn, 1, batch), 256, lds, s>>>(p);
-    } else if constexpr (C <= 128) {
-        // two lighter kernels that fit two waves per SIMD beat the fused one at one wave per SIMD
-        constexpr int lds_k = dkv_x3_lds<DQ, C, true, false>(), lds_v = dkv_x3_lds<DQ, C, false, true>();
-        if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, false, 2>, lds_k) || !allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, false, true, 2>, lds_v))
+    if constexpr (C <= 128) {
+        // two lighter kernels that fit two waves per SIMD beat a fused dK + dV kernel at one wave per SIMD
+        constexpr int lds_k = dkv_x3_lds<DQ, C, true, false, F16>(), lds_v = dkv_x3_lds<DQ, C, false, true, F16>();
+        if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, false, 2, F16>, lds_k) || !allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, false, true, 2, F16>, lds_v))
             return ddpm::fail_invalid("LDS size for attention backward (dk, dv)");
-        attn_bwd_dkv_x3_kernel<DQ, C, true, false, 2><<<dim3(bn, 1, batch), 256, lds_k, s>>>(p);
-        attn_bwd_dkv_x3_kernel<DQ, C, false, true, 2><<<dim3(bn, 1, batch), 256, lds_v, s>>>(p);
+        attn_bwd_dkv_x3_kernel<DQ, C, true, false, 2, F16><<<dim3(bn, 1, batch), 256, lds_k, s>>>(p);
+        attn_bwd_dkv_x3_kernel<DQ, C, false, true, 2, F16><<<dim3(bn, 1, batch), 256, lds_v, s>>>(p);
     } else {
         constexpr int CV = C > 128 ? 128 : C;
-        constexpr int lds_k = dkv_x3_lds<DQ, C, true, false>(), lds_v = dkv_x3_lds<DQ, CV, false, true>();
-        if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, false>, lds_k) || !allow_lds(attn_bwd_dkv_x3_kernel<DQ, CV, false, true, 2>, lds_v))
+        constexpr int lds_k = dkv_x3_lds<DQ, C, true, false, F16>(), lds_v = dkv_x3_lds<DQ, CV, false, true, F16>();
+        if (!allow_lds(attn_bwd_dkv_x3_kernel<DQ, C, true, false, 1, F16>, lds_k) || !allow_lds(attn_bwd_dkv_x3_kernel<DQ, CV, false, true, 2, F16>, lds_v))
             return ddpm::fail_invalid("LDS size for attention backward (dk, dv)");
-        attn_bwd_dkv_x3_kernel<DQ, C, true, false><<<dim3(bn, 1, batch), 256, lds_k, s>>>(p);
-        attn_bwd_dkv_x3_kernel<DQ, CV, false, true, 2><<<dim3(bn, C / CV, batch), 256, lds_v, s>>>(p);
+        attn_bwd_dkv_x3_kernel<DQ, C, true, false, 1, F16><<<dim3(bn, 1, batch), 256, lds_k, s>>>(p);
+        attn_bwd_dkv_x3_kernel<DQ, CV, false, true, 2, F16><<<dim3(bn, C / CV, batch), 256, lds_v, s>>>(p);
     }
-    constexpr int lds_q = dq_x3_lds<DQ, C>();
-    if (!allow_lds(attn_bwd_dq_x3_kernel<DQ, C>, lds_q)) return ddpm::fail_invalid("LDS size for attention backward (dq)");
-    attn_bwd_dq_x3_kernel<DQ, C><<<dim3(bn, 1, batch), 256, lds_q, s>>>(p);
+    constexpr int lds_q = dq_x3_lds<DQ, C, F16>();
+    if (!allow_lds(attn_bwd_dq_x3_kernel<DQ, C, F16>, lds_q)) return ddpm::fail_invalid("LDS size for attention backward (dq)");
+    attn_bwd_dq_x3_kernel<DQ, C, F16><<<dim3(bn, 1, batch), 256, lds_q, s>>>(p);
     return ddpm::check_launch("attn_bwd_x3");
+}
+
+template <int DQ, int C>
+int launch_bwd_x3(const BwdParams& p, int batch, hipStream_t s) {
+    if constexpr (DQ <= 16) {
+        if (ddpm::f16_math() && pair_in_training()) {
+            if (!p.range_flag) return DDPM_E_LAUNCH;
+            return launch_bwd_x3_math<DQ, C, true>(p, batch, s);
+        }
+    }
+    return launch_bwd_x3_math<DQ, C, false>(p, batch, s);
 }
 
 template <int DQ, int CT>
@@ -1291,6 +1440,7 @@ extern "C" int ddpm_attention_bwd(const float* qkv, const float* dy, int ldd, co
     p.dqp = dq;
     p.lq = 2 * dq + c;
     p.ldd = ldd;
+    p.range_flag = ddpm::f16_math() ? ddpm::range_flag() : nullptr;
     if (c == 64 && dq == 8) return launch_bwd_fast<8, 64>(p, batch, s);
     if (c == 128 && dq == 16) return launch_bwd_fast<16, 128>(p, batch, s);
     if (c == 256 && dq == 32 && ddpm::split_math()) return launch_bwd_x3<32, 256>(p, batch, s);

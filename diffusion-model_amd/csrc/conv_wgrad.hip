@@ -309,6 +309,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
     const int tap = PAIR ? 2 * tg + (c4 >> 4) : tg;
     const int wave_tap = PAIR == 1 ? 2 * tg + wn : (PAIR == 2 ? 2 * tg + wm : tg);
     const bool tap_ok = tap < p.taps;
+    // a layer with at most 64 channels on BOTH sides runs as PAIR = 1 with the lower half of the tile's rows empty: the
+    // waves of that half stage their share of the operands but issue no matrix instructions
+    const bool idle_wave = PAIR == 1 && __builtin_amdgcn_readfirstlane(wm * 64 >= p.m_total ? 1 : 0) != 0;
     int dy = 0, dx = 0;
     if (MODE == WG_CONV3) {
         dy = tap / 3 - 1;
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
-                mfma(k);
+                if (!idle_wave) mfma(k);
                 if (k < 8 && !(DDPM_WG_ABLATE & 1)) stage(k);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -554,7 +557,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 24; ++k) {
-                if (!(DDPM_WG_ABLATE & 8) || p.taps == 77) mfma(k);
+                if (idle_wave) {
+                } else if (!(DDPM_WG_ABLATE & 8) || p.taps == 77) mfma(k);
                 else acc[(k >> 1) & 1][k & 1][k & 15] += static_cast<float>(a[(k >> 1) & 1][k % 3][0]) + static_cast<float>(b[k & 1][k % 3][1]);
                 if ((k & 1) && (!(DDPM_WG_ABLATE & 1) || p.taps == 77)) stage(k >> 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -638,15 +642,18 @@ int clear_accumulator(float* out, int64_t n, hipStream_t s) {
 
 template <int MODE>
 int launch_wgrad(WgradParams& p, hipStream_t s) {
-    const bool big = p.m_total > 64 || p.n_total > 64;
-    const int bt = big ? 128 : 64;
-    p.m_tiles = (p.m_total + bt - 1) / bt;
-    p.n_tiles = (p.n_total + bt - 1) / bt;
-    // 64 channels on one side of a 3x3 layer: two taps share a tile (see the kernel)
+    // 64 channels on one side of a 3x3 layer: two taps share a tile (see the kernel); 64 (or fewer) on both sides:
+    // the same with half of the tile's rows empty, still ahead of the fp32 kernel's 64 x 64 tiles
     static const bool pairs_on = [] {   // DDPM_WGRAD_PAIR=0: diagnostic switch for A/B measurements
         const char* e = getenv("DDPM_WGRAD_PAIR");
         return !(e && strcmp(e, "0") == 0);
     }();
+    const bool small_pair = MODE == WG_CONV3 && ddpm::split_math() && pairs_on && p.m_total <= 64 && p.n_total <= 64 && p.m_total > 32 &&
+                            p.n_total > 32;
+    const bool big = p.m_total > 64 || p.n_total > 64 || small_pair;
+    const int bt = big ? 128 : 64;
+    p.m_tiles = (p.m_total + bt - 1) / bt;
+    p.n_tiles = (p.n_total + bt - 1) / bt;
     const int pair = (MODE == WG_CONV3 && big && ddpm::split_math() && pairs_on) ? (p.n_total <= 64 ? 1 : (p.m_total <= 64 ? 2 : 0)) : 0;
     p.tap_groups = pair ? (p.taps + 1) / 2 : p.taps;
     const int64_t tiles = static_cast<int64_t>(p.m_tiles) * p.n_tiles * p.tap_groups;

@@ -127,6 +127,21 @@ __global__ __launch_bounds__(256) void sinusoidal_kernel(const void* t, int t_is
     }
 }
 
+// rows 1 .. batch - 1 of the four outputs (and of the embedding itself) = row 0
+struct RowCopy {
+    float* out[5];
+    int width[5];
+    int batch;
+};
+__global__ __launch_bounds__(256) void replicate_row_kernel(const RowCopy a) {
+    float* __restrict__ p = a.out[blockIdx.y];
+    if (!p) return;
+    const int w = a.width[blockIdx.y];
+    const int64_t total = static_cast<int64_t>(a.batch - 1) * w;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * 256)
+        p[w + i] = p[i % w];
+}
+
 static float log_step_for(int emb_dim) {
     volatile float lg = std::log(10000.0f);
     return lg / static_cast<float>(emb_dim / 2 - 1);
@@ -168,6 +183,23 @@ extern "C" int ddpm_time_embed(const ddpm_embed_args* a, void* stream) {
         d.out[k] = a->out[k];
     }
     d.log_step = log_step_for(a->emb_dim);
+    if (a->uniform && a->batch > 1) {
+        DDPM_REQUIRE(a->n_labels <= 1);
+        d.batch = 1;
+        time_embed_kernel<<<dim3(1, 4), 256, 0, ddpm::as_stream(stream)>>>(d);
+        RowCopy rc;
+        rc.batch = a->batch;
+        for (int k = 0; k < 4; ++k) {
+            rc.out[k] = a->out[k];
+            rc.width[k] = a->ch[k];
+        }
+        rc.out[4] = a->emb_out;
+        rc.width[4] = a->emb_dim;
+        const int64_t most = static_cast<int64_t>(a->batch - 1) * (a->ch[3] > a->ch[0] ? a->ch[3] : a->ch[0]);
+        const int gx = static_cast<int>((most + 1023) / 1024 > 512 ? 512 : (most + 1023) / 1024);
+        replicate_row_kernel<<<dim3(gx < 1 ? 1 : gx, 5), 256, 0, ddpm::as_stream(stream)>>>(rc);
+        return ddpm::check_launch("time_embed_kernel (uniform)");
+    }
     time_embed_kernel<<<dim3((a->batch + kSamples - 1) / kSamples, 4), 256, 0, ddpm::as_stream(stream)>>>(d);
     return ddpm::check_launch("time_embed_kernel");
 }

@@ -402,13 +402,16 @@ class UNetEngine(TrainMixin):
         b, h, w = x.bhw
         call("ddpm_add_temb", x.ptr, x.ld, _ptr(temb), out.ptr, out.ld, b, h * w, x.c, _stream())
 
-    def time_embed(self, t, y, emb_out=None, defer_label_check=False):
+    def time_embed(self, t, y, emb_out=None, defer_label_check=False, uniform=False):
+        """The four (time [+ label]) embedding vectors per sample. uniform: the caller guarantees that every sample has the
+        same timestep (the sampling loop); with at most one label the rows are then equal and computed once."""
         B = t.shape[0]
         dev = t.device
         chans = [self.base, self.base * 2, self.base * 4, self.base * 8]
         outs = [torch.empty((B, c), device=dev, dtype=torch.float32) for c in chans]
         a = EmbedArgs()
         a.batch, a.emb_dim = B, self.emb
+        a.uniform = int(bool(uniform) and (y is None or y.numel() == 1))
         if t.dtype == torch.int64:
             a.t_is_float = 0
         elif t.dtype == torch.float32:
@@ -516,14 +519,16 @@ class UNetEngine(TrainMixin):
         math = conv_math()
         label = "attention_fwd<fp32>"
         if n >= 128 and c >= 64 and math != "fp32" and dqp <= 64:
-            label = "attention_fwd<fp16-pair>" if (math == "f16x2" and dqp <= 16 and lse is None) else "attention_fwd<split-bf16>"
+            pair = math == "f16x2" and dqp <= 16 and (lse is None or os.environ.get("DDPM_ATTN_TRAIN_F16", "1") != "0")
+            label = "attention_fwd<fp16-pair>" if pair else "attention_fwd<split-bf16>"
         self._launch(label, 2.0 * b * n * n * (dqp + c), "ddpm_attention_fwd", qkv.ptr, x.ptr, x.ld,
                      _ptr(self.T(key + ".gamma")), out.ptr, out.ld, _ptr(raw), _ptr(lse), _ptr(temb), b, n, c, dqp, _stream())
 
     # ------------------------------------------------------------------ whole network, eval mode
     def forward_eval(self, x, t, y=None, want_fms=True, step=None):
-        """Eval-mode forward. With `step` (a dict: c1, c2, c3, noise_mode, z, seed, call, eps_cond, cfg_w, out) the last
-        layer and the reverse ancestral step run as one kernel and the return value is x_{t-1} instead of eps-hat."""
+        """Eval-mode forward. With `step` (a dict: c1, c2, c3, noise_mode, z, seed, call, eps_cond, cfg_w, out, t_uniform)
+        the last layer and the reverse ancestral step run as one kernel and the return value is x_{t-1} instead of
+        eps-hat; t_uniform says that all entries of t are equal (the embedding is then computed once)."""
         B, cin, H, W = x.shape
         if cin != self.cin:
             raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
@@ -531,7 +536,7 @@ class UNetEngine(TrainMixin):
         dev = x.device
         bc = self.base
         v1 = self.v == 1
-        temb = self.time_embed(t, y)
+        temb = self.time_embed(t, y, uniform=bool(step is not None and step.get("t_uniform")))
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         fms = []
 

@@ -56,7 +56,7 @@ class TrainMixin:
     def _wgrad_label(kind, m, n):
         """Kernel family the library uses for a weight gradient (profiling label): tiles of 128 run on split operands."""
         math = conv_math()
-        split = (m > 64 or n > 64) and math != "fp32"
+        split = (m > 64 or n > 64 or (kind == "conv3x3" and 32 < m <= 64 and 32 < n <= 64)) and math != "fp32"
         return f"conv_wgrad<{kind},{('split-bf16' if math == 'bf16x3' else 'fp16-pair') if split else 'fp32'}>"
 
     # ------------------------------------------------------------------ gradient storage
@@ -328,7 +328,8 @@ class TrainMixin:
         e = torch.empty((b, n), device=dev, dtype=torch.float32)
         ws = self._workspace(dev)
         x3 = conv_math() != "fp32" and (c, dqp) in ((64, 8), (128, 16), (256, 32))
-        self._launch("attention_bwd<split-bf16>" if x3 else "attention_bwd<fp32>", 2.0 * b * n * n * (2 * dqp + 2 * c + dqp + c), "ddpm_attention_bwd", qkv.ptr, dout.ptr, dout.ld,
+        pair = x3 and conv_math() == "f16x2" and dqp <= 16 and os.environ.get("DDPM_ATTN_TRAIN_F16", "1") != "0"
+        self._launch(("attention_bwd<fp16-pair>" if pair else "attention_bwd<split-bf16>") if x3 else "attention_bwd<fp32>", 2.0 * b * n * n * (2 * dqp + 2 * c + dqp + c), "ddpm_attention_bwd", qkv.ptr, dout.ptr, dout.ld,
                      _ptr(rec["raw"]), _ptr(rec["lse"]), _ptr(self.T(key + ".gamma")), _ptr(ws), _ptr(e), dqkv.ptr, _ptr(dgamma), b, n, c,
                      dqp, _stream())
         grads[key + ".gamma"] = dgamma

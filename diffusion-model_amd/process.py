@@ -126,7 +126,8 @@ class _DiffusionBase:
                     z = torch.randn_like(x_t)                # per-step noise from the device generator
             if fused:
                 # the UNet's final 1x1 conv and the update are one kernel: eps-hat is consumed where it is produced
-                step = dict(c1=c1, c2=c2, c3=c3, noise_mode=0 if t == 0 else (2 if philox else 1), z=z, seed=seed, call=t)
+                step = dict(c1=c1, c2=c2, c3=c3, noise_mode=0 if t == 0 else (2 if philox else 1), z=z, seed=seed, call=t,
+                            t_uniform=True)      # t_tensor is torch.full: one embedding row serves the whole batch
                 x_t = x_t.contiguous()
                 if cfg_scale > 0:
                     step.update(eps_cond=self._model_call(x_t, t_tensor, labels).contiguous(), cfg_w=float(cfg_scale))

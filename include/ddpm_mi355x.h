@@ -185,7 +185,9 @@ typedef struct ddpm_embed_args {
     int32_t n_classes;      /* rows of label_table (required when n_labels > 0). A label outside
                                [0, n_classes) is never dereferenced: that sample's four output rows
                                are filled with NaN (nn.Embedding raises there; a kernel cannot) */
-    int32_t reserved;
+    int32_t uniform;        /* != 0: the caller guarantees that all B timesteps are equal (and n_labels <= 1), as in
+                               every step of the sampling loop (first-iteration/diffusion.py:22-24): row 0 is computed
+                               once and copied to the other rows (same bits as computing each row) */
     const void* t;          /* device [B] int64 (or fp32) */
     const int64_t* y;       /* device [n_labels] or NULL */
     const float* label_table; /* device [num_classes][E] or NULL */

@@ -10,7 +10,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 for wl in train sample; do
   if [ $wl = train ]; then export DDPM_SIDE_STREAM=0; else unset DDPM_SIDE_STREAM; fi
-  timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $out/prof_$wl -o r -- python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > $out/prof_$wl.log 2>&1 || { tail -20 $out/prof_$wl.log; exit 1; }
+  timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $out/prof_$wl -o r -- python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-full-call --no-full-range --settle 0.5 > $out/prof_$wl.log 2>&1 || { tail -20 $out/prof_$wl.log; exit 1; }
   db=$(ls $out/prof_$wl/*.db | head -1)
   python tools/rocpd_stats.py $db > $out/$wl.stats.txt || exit 1
   rm -f $out/prof_$wl/*.db
