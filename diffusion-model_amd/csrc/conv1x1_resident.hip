@@ -240,7 +240,7 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
                     for (int e = 0; e < 16; ++e) {
                         const unsigned row = static_cast<unsigned>((e & 3) + 8 * (e >> 2) + hq);
                         if (!(DDPM_C1R_ABLATE & 1) || v[e] == 1.2345f)
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, row * ldo4 + n4, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, row * ldo4 + n4, 0, DDPM_STORE_AUX);
                     }
                 }
                 zero(master[j]);
@@ -476,7 +476,7 @@ __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned cha
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             const unsigned row = static_cast<unsigned>((e & 3) + 8 * (e >> 2) + hq);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, row * ldo4 + n4, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, row * ldo4 + n4, 0, DDPM_STORE_AUX);
                         }
                     }
                     zero(master[j]);

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const unsigned rel = static_cast<unsigned>(i * WM * 32 + 8 * (e >> 2) + (e & 3));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, vo + rel * ldo4, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, vo + rel * ldo4, 0, DDPM_STORE_AUX);
                 }
                 if constexpr (STATS) {
                     float s1 = 0.f, s2 = 0.f;

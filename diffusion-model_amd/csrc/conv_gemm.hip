@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const unsigned rel = static_cast<unsigned>(i * 64 + (e & 3) + 8 * (e >> 2));
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, vo + rel * ldo4, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, vo + rel * ldo4, 0, DDPM_STORE_AUX);
                     }
                 }
             }

@@ -39,7 +39,7 @@ class TrainMixin:
     _s2 = None                                                      # second stream of the backward pass (weight gradients)
     _main_stream = None                                             # the stream the backward itself runs on (set when _s2 is used)
     _use_side = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # diagnostic switch: "0" keeps the backward on one stream
-    _fused_stats = os.environ.get("DDPM_BN_FUSED", "0") == "1"     # BatchNorm statistics summed in the 3x3 convolution's epilogue
+    _fused_stats = os.environ.get("DDPM_BN_FUSED", "1") != "0"     # BatchNorm statistics summed in the 3x3 convolution's epilogue (no separate pass over its output); "0": diagnostic switch
     _gall = ()          # gradient tensors this backward allocated itself (not slices of an averager's buffer)
     _gstate = None      # three device floats: largest |incoming gradient|, the backward's power-of-two scale, its inverse
 

@@ -7,6 +7,8 @@ property at full width: an eval-mode forward does not depend on how the batch is
 Tolerances as in the golden-vector tests: forward 5e-5 of tensor scale (1e-4 in train mode),
 gradients 2e-3 of each tensor's max + 5e-6.
 """
+import os
+
 import pytest
 import torch
 
@@ -146,8 +148,15 @@ def _full_size_case(seed):
         gen = torch.Generator(device="cpu").manual_seed(1000 + seed)
         x, tgt = torch.randn((256, 1, 28, 28), generator=gen), torch.randn((256, 1, 28, 28), generator=gen)
         t = torch.randint(0, 1000, (256,), generator=gen)
-        loss64, g64, _, _ = O.loss_and_grads(sd64, 2, x.double(), t, tgt.double())
-        _, g32, _, _ = O.loss_and_grads(sd32, 2, x, t, tgt)
+        # (another test module pins torch to one CPU thread at import, which holds for the whole pytest process: the two
+        # oracle runs of a seed take a minute on one thread and ten seconds on the box's CPU share)
+        threads = torch.get_num_threads()
+        torch.set_num_threads(max(threads, min(16, int(os.environ.get("OMP_NUM_THREADS", "8")))))
+        try:
+            loss64, g64, _, _ = O.loss_and_grads(sd64, 2, x.double(), t, tgt.double())
+            _, g32, _, _ = O.loss_and_grads(sd32, 2, x, t, tgt)
+        finally:
+            torch.set_num_threads(threads)
         own = {k: (g32[k].double() - g64[k]).abs().max().item() for k in g64}
         _full_size_cache[seed] = (sd32, x, t, tgt, loss64.item(), g64, own)
         print(f"[full-size train step] CPU oracle of seed {seed} done (float64 and float32)", flush=True)

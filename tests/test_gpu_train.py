@@ -247,3 +247,15 @@ def test_adam_rejects_what_it_does_not_implement():
     cpu.grad = torch.zeros(4)
     with pytest.raises(RuntimeError):
         Adam([cpu]).step()
+
+
+def test_backward_storage_trace_matches_the_committed_one():
+    """tests/golden/backward_trace.json is what the CPU-side data-parallel test (tests/test_parallel_gloo.py) replays
+    through the gradient averager: it must be the sequence of storage requests and flush points the engine's backward
+    produces today (regenerate with `python tests/trace_util.py` on a GPU box when the schedule changes)."""
+    from trace_util import load_traces, record_traces
+    want, got = load_traces(), record_traces()
+    assert sorted(got) == sorted(want)
+    for name in want:
+        assert got[name]["parameters"] == want[name]["parameters"], name
+        assert [list(e) for e in got[name]["events"]] == [list(e) for e in want[name]["events"]], name

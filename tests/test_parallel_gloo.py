@@ -9,6 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from diffusion_model_amd import parallel
+from trace_util import load_traces
 
 
 def test_shard_range_partitions_exactly():
@@ -101,6 +102,74 @@ def _check_bucketed_averager(rank, world):
     assert m._engine.grad_sink is None
 
 
+class ReplayEngine:
+    """What BucketedGradientAverager needs of the UNet's engine, on CPU tensors: no side stream."""
+    grad_sink = None
+    dist_group = None
+    _s2 = None
+
+
+class ReplayModel(torch.nn.Module):
+    """One flat parameter per gradient-storage request of the recorded backward, in the order of the requests."""
+
+    def __init__(self, sizes):
+        super().__init__()
+        self.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(n)) for n in sizes])
+        self._engine = ReplayEngine()
+
+
+def _check_real_backward_trace(rank, world):
+    """The REAL sequence of storage requests and flush points of engine_train's backward (recorded on the GPU from the
+    full-width second-iteration UNet: 12.3 M parameters in 100-odd slices, tests/golden/backward_trace.json), replayed
+    through the real averager with 8 MiB buckets: every gradient comes out as the mean over the ranks, the buckets are
+    cut only at flush points, all but the last hold at least 8 MiB, and together they cover the flat buffer once."""
+    trace = load_traces()["v2_full_width_28"]
+    events = [tuple(e) for e in trace["events"]]
+    sizes = [e[1] for e in events if e[0] == "alloc"]
+    assert sum(sizes) >= trace["parameters"] and len(sizes) > 90
+    m = ReplayModel(sizes)
+    avg = parallel.BucketedGradientAverager(m, bucket_bytes=8 << 20).attach()
+    sent = []
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        if avg.flat is not None and t.untyped_storage().data_ptr() == avg.flat.untyped_storage().data_ptr():
+            sent.append((t.storage_offset(), t.numel()))
+        return real_all_reduce(t, *a, **k)
+
+    names = [n for n, _ in m.named_parameters()]
+    mean = sum(r + 1 for r in range(world)) / world
+    dist.all_reduce = counting_all_reduce
+    try:
+        for step in range(3):                       # step 0 records the layout, steps 1-2 run in buckets
+            del sent[:]
+            grads, i, flush_offsets = {}, 0, []
+            for ev in events:
+                if ev[0] == "alloc":
+                    g = avg.alloc(ev[1], torch.device("cpu"))
+                    g.fill_(float((rank + 1) * (i % 7 + 1)))
+                    grads[names[i]] = g
+                    i += 1
+                else:
+                    avg.flush(m._engine)
+                    flush_offsets.append(avg._off)
+            if not avg.takes_over(grads):
+                for n, p in m.named_parameters():
+                    p.grad = grads[n]
+            avg.finish()
+            for i, (n, p) in enumerate(m.named_parameters()):
+                assert torch.all(p.grad == mean * (i % 7 + 1)), (step, n)
+            if step > 0:
+                assert len(sent) >= 5, sent                                            # 49 MB in 8 MiB buckets
+                assert sent[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(sent, sent[1:]))
+                assert sent[-1][0] + sent[-1][1] == avg.flat.numel() == sum(avg.sizes)
+                assert all(n >= (8 << 20) // 4 for _, n in sent[:-1])
+                assert all(off + n in flush_offsets or (off + n == avg.flat.numel()) for off, n in sent)   # cut at flush points only
+    finally:
+        dist.all_reduce = real_all_reduce
+    avg.detach()
+
+
 def _worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -119,6 +188,7 @@ def _worker(rank, world, port, tmp):
         assert torch.allclose(lin.bias.grad, local[1])                 # identical on all ranks
         assert torch.equal(lin.weight.detach(), w0)
         _check_bucketed_averager(rank, world)
+        _check_real_backward_trace(rank, world)
         # sharded sampling
         g = torch.Generator().manual_seed(1)
         shape = (5, 1, 4, 4)                                           # odd batch: uneven shards
