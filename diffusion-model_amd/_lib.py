@@ -140,20 +140,27 @@ def packed_floats(taps, rows, cin):
 
 
 MATH_MODES = ("fp32", "bf16x3", "f16x2")
+_mode = None      # the library's current mode as this module last read or set it (this module is its only writer)
 
 
 def conv_math():
     """Arithmetic of the MFMA-fed kernels that the library is in right now: 'fp32', 'bf16x3' or 'f16x2' (it starts
-    in the one DDPM_CONV_MATH names; set_conv_math / math_scope change it)."""
-    return MATH_MODES[int(lib().ddpm_conv_math())]
+    in the one DDPM_CONV_MATH names; set_conv_math / math_scope change it). Asked on every launch and cache lookup of
+    the host mirror, hence answered from a copy kept here instead of a call into the library."""
+    global _mode
+    if _mode is None:
+        _mode = MATH_MODES[int(lib().ddpm_conv_math())]
+    return _mode
 
 
 def set_conv_math(mode):
     """Switch the library's arithmetic; returns the previous mode. Packed weights belong to the mode they were
     packed in: callers key their caches on conv_math()."""
+    global _mode
     prev = conv_math()
     if mode != prev:
         call("ddpm_set_conv_math", MATH_MODES.index(mode))
+        _mode = mode
     return prev
 
 
