@@ -43,6 +43,20 @@ class TrainMixin:
     _gall = ()          # gradient tensors this backward allocated itself (not slices of an averager's buffer)
     _gstate = None      # three device floats: largest |incoming gradient|, the backward's power-of-two scale, its inverse
 
+    _shards_checked = False
+
+    def _check_equal_shards(self, batch):
+        """Global-batch BatchNorm and the gradient mean over ranks both assume that every rank holds the same number of
+        samples. Checked once, at this network's first training step under sync_bn (which all ranks reach together):
+        a global batch that does not divide by the world size fails here instead of training on skewed statistics."""
+        import torch.distributed as dist
+        sizes = [None] * dist.get_world_size(self.dist_group)
+        dist.all_gather_object(sizes, int(batch), group=self.dist_group)
+        self._shards_checked = True
+        if len(set(sizes)) != 1:
+            raise ValueError(f"sync_bn needs the same number of samples on every rank, got {sizes}: cut the global batch evenly "
+                             "(or train with sync_bn = False, per-rank statistics)")
+
     # ------------------------------------------------------------------ scratch
     def _workspace(self, dev):
         ws = getattr(self, "_ws", None)
@@ -161,6 +175,8 @@ class TrainMixin:
             raise RuntimeError(f"expected {self.cin} input channels, got {cin}")
         x = x.contiguous()
         dev = x.device
+        if self.sync_bn and not self._shards_checked and _dist_active():
+            self._check_equal_shards(B)
         self.prepack_conv3()          # every 3x3 weight the optimizer has changed, both orientations, in one launch
         bc, v1 = self.base, self.v == 1
         emb = torch.empty((B, self.emb // 2 * 2), device=dev, dtype=torch.float32)

@@ -155,6 +155,16 @@ def main():
     if rank == 0:
         assert torch.equal(both[-1][0][:2], alone[-1][0])
 
+    # ---- 6: global-batch BatchNorm refuses shards of different sizes ---------------------------------------------
+    m = build(2, 2).train()
+    m._engine.sync_bn = True
+    n_mine = 2 if rank == 0 else 1
+    try:
+        m(x[:n_mine].cuda(), t[:n_mine].cuda())
+        raise AssertionError("uneven shards were accepted")
+    except ValueError as e:
+        assert "same number of samples" in str(e), e
+
     dist.barrier()
     if rank == 0:
         print("DP_WORKER_OK", flush=True)

@@ -152,6 +152,29 @@ def test_label_kernels_never_dereference_a_bad_label():
     assert torch.all(tab_bad[3] == 0) and torch.any(tab_good[3] != 0)
 
 
+@pytest.mark.parametrize("with_label", [False, True])
+@pytest.mark.parametrize("batch", [1, 5, 512])
+def test_embedding_of_a_uniform_step_equals_the_per_sample_one(batch, with_label):
+    """A sampling step hands every sample the same t (and at most one label, third-iteration/diffusion.py:34-37): the
+    embedding rows are then computed once and replicated, and must be the bits the per-sample kernel gives."""
+    m, _ = _tiny_v3()
+    eng = m._engine
+    t = torch.full((batch,), 737, dtype=torch.long, device="cuda")
+    y = torch.tensor([7]).cuda() if with_label else None
+    emb_a, emb_b = (torch.full((batch, eng.emb), float("nan"), device="cuda") for _ in range(2))
+    per_sample = eng.time_embed(t, y, emb_out=emb_a, uniform=False)
+    once = eng.time_embed(t, y, emb_out=emb_b, uniform=True)
+    assert torch.equal(emb_a, emb_b) and torch.isfinite(emb_a).all()
+    for a, b in zip(per_sample, once):
+        assert a.shape == b.shape and torch.equal(a, b) and torch.isfinite(a).all()
+    # per-sample labels are not uniform whatever the flag says: the mirror falls back to the per-sample kernel
+    if with_label and batch > 1:
+        ys = (torch.arange(batch) % 10).cuda()
+        a = eng.time_embed(t, ys, uniform=False)
+        b = eng.time_embed(t, ys, uniform=True)
+        assert all(torch.equal(u, v) for u, v in zip(a, b)) and not torch.equal(a[0][0], a[0][1])
+
+
 def test_eval_after_a_train_forward_without_optimizer_step_uses_fresh_running_statistics():
     """eval -> train-mode forward under no_grad (updates running_mean / running_var in place) -> eval: the second eval
     must see the updated statistics (the folded scale/shift pairs are cached)."""
