@@ -1,7 +1,9 @@
 #!/bin/bash
-# A/B of the built library against another build of it: tools/ab_lib.sh <other.so> <microbench args...>, e.g.
-#   tools/ab_lib.sh ablate_build/lib_base_bwd.so attn 256 784 128 50
-set -o pipefail
-other=$1; shift
-echo -n "this build: "; timeout -k 10 90 python tools/microbench.py "$@" 2>/dev/null | tr '\n' ';'; echo
-echo -n "$other: "; DDPM_LIB=$PWD/$other timeout -k 10 90 python tools/microbench.py "$@" 2>/dev/null | tr '\n' ';'; echo
+# A/B of two builds of the library on one box, alternating: tools/ab_lib.sh <other.so> <workload> [rounds] [extra bench args]
+# prints ms/step of the shipped library and of the other one per round.
+other=$1; wl=${2:-train}; rounds=${3:-3}; shift 3 || true
+for i in $(seq 1 $rounds); do
+  a=$(timeout -k 10 200 python bench.py --workload $wl --steps 20 --no-cpu-baseline --no-full-call --no-full-range "$@" 2>&1 >/dev/null | grep -o "[0-9.]* ms/step" | tail -1) || exit 1
+  b=$(DDPM_LIB=$other timeout -k 10 200 python bench.py --workload $wl --steps 20 --no-cpu-baseline --no-full-call --no-full-range "$@" 2>&1 >/dev/null | grep -o "[0-9.]* ms/step" | tail -1) || exit 1
+  echo "$wl round $i: shipped $a   other $b"
+done

@@ -4,6 +4,7 @@
     python tools/microbench.py conv3x3 B H W Cin Cout [iters]
     python tools/microbench.py wgrad   B H W Cin Cout [iters]
     python tools/microbench.py conv1x1 B H W Cin Cout [iters]
+    python tools/microbench.py convT   B H W Cin Cout [iters]  (2x2 stride-2 transposed conv into the right half of a [B,2H,2W,2*Cout] buffer)
     python tools/microbench.py attn    B N C [iters]         (forward + backward)
     python tools/microbench.py step    NELEMS [iters]        (reverse-step kernel, HBM-bound)
 Prints the average launch time from HIP events and the achieved TFLOP/s or GB/s.
@@ -77,6 +78,24 @@ def main():
         t = timeit(lambda: call("ddpm_conv1x1_fwd", C.byref(d), P(x), None, P(wp), C.byref(ep), P(y), S()), iters)
         gb = 4.0 * B * H * W * (ci + co)
         print(f"conv1x1 B={B} {H}x{W} {ci}->{co}: {t*1e6:.1f} us  {2.0*B*H*W*ci*co/t/1e12:.1f} TFLOP/s  {gb/t/1e12:.2f} TB/s algorithmic")
+    elif kind == "convT":
+        B, H, W, ci, co = a[:5]
+        iters = a[5] if len(a) > 5 else 20
+        x = torch.randn(B, H, W, ci, device=dev)
+        w = torch.randn(ci, co, 2, 2, device=dev) * ci ** -0.5
+        wp = torch.empty(packed_floats(1, 4 * co, ci), device=dev)
+        call("ddpm_pack_convT2x2", P(w), ci, co, P(wp), S())
+        cat = torch.zeros(B, 2 * H, 2 * W, 2 * co, device=dev)
+        right = cat[..., co:]
+        d = ConvDesc(batch=B, in_h=H, in_w=W, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=2 * co, act=0, ldr=0, out_h=2 * H, out_w=2 * W,
+                     off_y=0, off_x=0)
+        sh = torch.zeros(co, device=dev)
+        ep = Epilogue(None, P(sh), None, None)
+        t = timeit(lambda: call("ddpm_convT2x2_fwd", C.byref(d), P(x), P(wp), C.byref(ep), C.c_void_p(right.data_ptr()), S()), iters)
+        gb = 4.0 * B * H * W * (ci + 4 * co)
+        import hashlib
+        digest = hashlib.sha1(cat.cpu().numpy().tobytes()).hexdigest()[:12] if B * H * W * co <= (1 << 26) else "-"
+        print(f"convT B={B} {H}x{W} {ci}->{co}: {t*1e6:.1f} us  {2.0*B*H*W*ci*4*co/t/1e12:.1f} TFLOP/s  {gb/t/1e12:.2f} TB/s algorithmic  {digest}")
     elif kind == "attn":
         B, N, c = a[:3]
         iters = a[3] if len(a) > 3 else 10
