@@ -20,7 +20,7 @@ constexpr int BM = 128;                // rows of a full tile (4 groups)
 constexpr unsigned OOB = 0x80000000u;  // any offset >= the descriptor's num_records reads as zero
 constexpr int kSlots = 512;            // resident workgroups: 256 CUs x 2 (LDS-limited)
 #ifndef DDPM_STORE_AUX
-#define DDPM_STORE_AUX 0               // cache policy of the epilogues' output stores (diagnostic builds: 2 = non-temporal)
+#define DDPM_STORE_AUX 2               // cache policy of the epilogues' output stores: 2 = non-temporal (0.3-0.7 % of a step against 0, the default policy; same bits)
 #endif
 #ifndef DDPM_ABLATE
 #define DDPM_ABLATE 0                  // diagnostic builds only: 1 = no staging in the K loop, 2 = also no barrier, 3 = no MFMAs, 4 = loads but no LDS stores, 5 = LDS stores but no loads
