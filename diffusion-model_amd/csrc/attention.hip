@@ -265,13 +265,13 @@ __device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4
 }
 
 // (the same with the range watch of conv_common.h: for q, k and v, which come from memory; probabilities need none)
-__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, float& amax) {
+__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, ddpm::conv::RangeWatch& amax) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[2 * e], v[2 * e + 1]});
     split8_f16(v, hi, lo);
 }
 
-__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, int plane_stride, float& amax) {
+__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, int plane_stride, ddpm::conv::RangeWatch& amax) {
     unsigned h0, l0, h1, l1;
     ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[0], v[1]});
     ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[2], v[3]});
@@ -301,7 +301,7 @@ using ddpm::conv::mfma16;
 template <int DQ, int QB, int NCT, bool F16>
 __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnParams p) {
     if constexpr (F16) ddpm::conv::fp16_saturate();
-    float amax = 0.f;                           // F16: largest magnitude of q, k, v this thread has turned into an fp16 pair
+    ddpm::conv::RangeWatch amax;                           // F16: largest magnitude of q, k, v this thread has turned into an fp16 pair
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     constexpr int NPL = F16 ? 2 : 3;            // operand planes
     constexpr int CS = 32 * NCT;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
 template <int DQ, int NCT, int NW, bool F16>
 __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const AttnParams p) {
     if constexpr (F16) ddpm::conv::fp16_saturate();
-    float amax = 0.f;                   // F16: largest magnitude of q, k, v this thread has turned into an fp16 pair
+    ddpm::conv::RangeWatch amax;                   // F16: largest magnitude of q, k, v this thread has turned into an fp16 pair
     const dim3 bid = ddpm::xcd_block();
     constexpr int NPL = F16 ? 2 : 3;    // operand planes
     constexpr int NPR = F16 ? 3 : 6;    // MFMAs per fragment pair

@@ -709,7 +709,7 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst, 
 }
 
 // The same for the fp16 pair: two planes; `amax` is the thread's range watch (conv_common.h).
-__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, float& amax) {
+__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, ddpm::conv::RangeWatch& amax) {
     unsigned hh[4], ll[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -721,7 +721,7 @@ __device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4
     lo = u32x4{ll[0], ll[1], ll[2], ll[3]};
 }
 
-__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, int plane_stride, float& amax) {
+__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, int plane_stride, ddpm::conv::RangeWatch& amax) {
     unsigned h0, l0, h1, l1;
     ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[0], v[1]});
     ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[2], v[3]});
@@ -733,7 +733,7 @@ __device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* d
 
 // 8 floats at p (two float4; zeros when !ok), times `scale` -> the operand's planes (pl[2] unused by the fp16 pair)
 template <bool F16>
-__device__ __forceinline__ void load_split8(const float* p, bool ok, u32x4 (&pl)[F16 ? 2 : 3], float scale, float& amax) {
+__device__ __forceinline__ void load_split8(const float* p, bool ok, u32x4 (&pl)[F16 ? 2 : 3], float scale, ddpm::conv::RangeWatch& amax) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -750,13 +750,13 @@ __device__ __forceinline__ void load_split8(const float* p, bool ok, u32x4 (&pl)
 }
 
 template <bool F16>
-__device__ __forceinline__ void split8_any(const float (&v)[8], u32x4 (&pl)[F16 ? 2 : 3], float& amax) {
+__device__ __forceinline__ void split8_any(const float (&v)[8], u32x4 (&pl)[F16 ? 2 : 3], ddpm::conv::RangeWatch& amax) {
     if constexpr (F16) split8_f16(v, pl[0], pl[1], amax);
     else split8(v, pl[0], pl[1], pl[2]);
 }
 
 template <bool F16>
-__device__ __forceinline__ void split4_store_any(const f32x4 v, unsigned char* dst, int plane_stride, float& amax) {
+__device__ __forceinline__ void split4_store_any(const f32x4 v, unsigned char* dst, int plane_stride, ddpm::conv::RangeWatch& amax) {
     if constexpr (F16) split4_store_f16(v, dst, plane_stride, amax);
     else split4_store(v, dst, plane_stride);
 }
@@ -795,7 +795,7 @@ __device__ __forceinline__ int swz(int row, int ch) { return 256 * row + 16 * (c
 template <int DQ, int CT, bool DK, bool DV, int WPS = 1, bool F16 = false>
 __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdParams p) {
     if constexpr (F16) ddpm::conv::fp16_saturate();
-    float amax = 0.f;                     // F16: largest magnitude this thread has turned into an fp16 pair
+    ddpm::conv::RangeWatch amax;                     // F16: largest magnitude this thread has turned into an fp16 pair
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     static_assert(!DV || CT <= 128, "transposed dO reads assume 256-byte rows");
     using PR = Products<F16>;
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
     // Q tile: QROW-byte rows of KD depth values; with KD = 16 the second column group (depth rows >= 16) is never stored
     const int qtr = (4 * h + tq) * QROW + tp * 8 + (KD > 16 ? tg * 32 : 0);
 
-    float amax_ds = 0.f;   // largest |dS| split by this lane; counts only if the lane's key exists
+    ddpm::conv::RangeWatch amax_ds;   // largest |dS| split by this lane; counts only if the lane's key exists
     const int qtiles = (p.n + TQ - 1) / TQ;
     load_tile(0);
     __syncthreads();
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
                 }
                 // (range watch: probabilities are at most 1 on real keys and need none; a key past the end holds
                 // exp(-lse), possibly infinite, in a column that is never stored, and must not raise the flag either)
-                float unwatched = 0.f;
+                ddpm::conv::RangeWatch unwatched;
                 if (DV) split8_any<F16>(pv, pp[ck], unwatched);
                 if (DK) split8_any<F16>(dsv, ds[ck], amax_ds);
             }
@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
         __syncthreads();
     }
 
-    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, k_ok ? __builtin_fmaxf(amax, amax_ds) : amax);
+    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, k_ok ? ddpm::conv::merged(amax, amax_ds) : amax);
     if (!wave_active || !k_ok) return;
     float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + kj) * p.lq;
     if (DV) {
@@ -1110,7 +1110,7 @@ constexpr int dkv_x3_lds() {
 template <int DQ, int CT, bool F16 = false>
 __global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(const BwdParams p) {
     if constexpr (F16) ddpm::conv::fp16_saturate();
-    float amax = 0.f;                     // F16: largest magnitude this thread has turned into an fp16 pair
+    ddpm::conv::RangeWatch amax;                     // F16: largest magnitude this thread has turned into an fp16 pair
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
     using PR = Products<F16>;
     constexpr int NPL = F16 ? 2 : 3;

@@ -90,7 +90,7 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
     const int g_begin = __builtin_amdgcn_readfirstlane(blockIdx.x * p.gpb);
     const int g_end = __builtin_amdgcn_readfirstlane(min(p.groups_total, g_begin + p.gpb));
     if (g_begin + wr >= g_end) return;
-    float amax = 0.f;   // F16: largest magnitude this thread has turned into an fp16 pair
+    RangeWatch amax;   // F16: largest magnitude this thread has turned into an fp16 pair
 
     const int kc16 = p.kc16;
     const int ntile = (g_end - g_begin - wr + 3) >> 2;        // row groups g_begin + wr, + 4, ...
@@ -372,7 +372,7 @@ __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned cha
         zero(acc[j]);
         zero(master[j]);
     }
-    float amax = 0.f;   // F16: largest magnitude this thread has turned into an fp16 pair
+    RangeWatch amax;   // F16: largest magnitude this thread has turned into an fp16 pair
 
     // step c (0..3) of the current slab
     auto step = [&](int c, f32x4 (&raw)[2], u32x4 (&b0cur)[NBW], u32x4 (&b0next)[NBW]) {

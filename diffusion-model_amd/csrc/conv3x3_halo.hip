@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     __shared__ __attribute__((aligned(16))) int rowb[256];   // sample index of every tile row, -1 = no such pixel
     if constexpr (F16) fp16_saturate();
-    float amax = 0.f;                           // F16: largest magnitude this thread has turned into an fp16 pair
+    RangeWatch amax;                           // F16: largest magnitude this thread has turned into an fp16 pair
     constexpr int XR = F16 ? XROW_F16 : XROW;   // LDS bytes per tile row
     constexpr int NPL = F16 ? 2 : 3;            // operand planes
 

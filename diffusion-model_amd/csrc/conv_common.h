@@ -139,8 +139,8 @@ constexpr float kLoInv = 1.0f / 2048.0f;
 constexpr int XROW_F16 = 80;   // LDS bytes per tile row: two planes of 16 fp16 and 16 bytes of padding (conflict-free 16-byte reads)
 
 // MODE.FP16_OVFL = 1 for the calling wave (the MODE register is per-wave state, set afresh at every launch): a
-// float -> fp16 conversion that overflows gives +-65504 instead of infinity, true infinities and NaNs pass through
-// (tools/probe/fp16_ovfl.hip). Every kernel that forms fp16 pairs calls this first, so that an operand beyond fp16's
+// float -> fp16 conversion that overflows gives +-65504 instead of infinity (tools/probe/fp16_ovfl.hip); the conversion
+// passes true infinities and NaNs through, but the matrix instructions of such a wave do not (see RangeWatch below). Every kernel that forms fp16 pairs calls this first, so that an operand beyond fp16's
 // range is clipped to +-65536 (hi = 65504, remainder 65504 / 2048) instead of turning into inf - inf = NaN inside
 // the matrix instructions: an untrained network's samples, which grow to 1e7 over a 1000-step loop, stay finite as
 // they do in fp32.
@@ -155,18 +155,32 @@ static __device__ __forceinline__ void split2_pair(const f32x2 v, unsigned& hi, 
 }
 
 // Range watch of the fp16-pair kernels: every thread keeps the largest magnitude it has turned into a pair (one
-// three-operand maximum per two elements) and, when it leaves, raises the library's range flag if that magnitude is
-// beyond fp16's largest finite value, i.e. if one of ITS operands was clipped. NaNs do not raise it (they are not
-// clipped either: they pass through the matrix instructions as they would in fp32).
-static __device__ __forceinline__ void watch2(float& amax, const f32x2 v) {
-    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])));
+// three-operand maximum per two elements) and whether it met a NaN (one unordered compare per two elements, kept as a
+// lane mask in scalar registers), and, when it leaves, raises the library's range flag if one of ITS operands was not
+// representable: beyond fp16's largest finite value (clipped), infinite, or NaN. The last two matter because a wave
+// with MODE.FP16_OVFL set does not propagate them: v_mfma_f32_32x32x16_f16 then treats a NaN operand as a finite
+// number and clamps what an infinite one produces (tools/probe/nan_mfma.hip), where fp32 arithmetic would hand the
+// NaN on. With the flag raised the caller repeats the work on three bf16 planes, which do propagate them.
+struct RangeWatch {
+    float amax = 0.f;
+    bool nan = false;
+};
+static __device__ __forceinline__ void watch2(RangeWatch& w, const f32x2 v) {
+    w.amax = __builtin_fmaxf(w.amax, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])));
+    w.nan |= __builtin_isunordered(v[0], v[1]);
 }
-static __device__ __forceinline__ void raise_range_flag(unsigned* flag, float amax) {
-    if (amax > 65504.0f) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+static __device__ __forceinline__ RangeWatch merged(const RangeWatch& a, const RangeWatch& b) {
+    RangeWatch w;
+    w.amax = __builtin_fmaxf(a.amax, b.amax);
+    w.nan = a.nan || b.nan;
+    return w;
+}
+static __device__ __forceinline__ void raise_range_flag(unsigned* flag, const RangeWatch& w) {
+    if (w.amax > 65504.0f || w.nan) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // four consecutive channels of one tile row -> the two fp16 planes of that row (8 bytes each, 32 bytes apart)
-static __device__ __forceinline__ void split_store_f16(const f32x4 v, unsigned char* dst, float& amax) {
+static __device__ __forceinline__ void split_store_f16(const f32x4 v, unsigned char* dst, RangeWatch& amax) {
     unsigned h0, l0, h1, l1;
     watch2(amax, f32x2{v[0], v[1]});
     watch2(amax, f32x2{v[2], v[3]});
@@ -177,7 +191,7 @@ static __device__ __forceinline__ void split_store_f16(const f32x4 v, unsigned c
 }
 
 // 8 consecutive fp32 (two 16-byte loads) -> the two fp16 planes of an MFMA operand fragment
-static __device__ __forceinline__ void split8_f16(const f32x4 v0, const f32x4 v1, u32x4& hi, u32x4& lo, float& amax) {
+static __device__ __forceinline__ void split8_f16(const f32x4 v0, const f32x4 v1, u32x4& hi, u32x4& lo, RangeWatch& amax) {
     unsigned h[4], l[4];
     watch2(amax, f32x2{v0[0], v0[1]});
     watch2(amax, f32x2{v0[2], v0[3]});

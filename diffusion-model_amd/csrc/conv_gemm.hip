@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams p) {
 template <int BN, int MODE, bool DUAL, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p) {
     if constexpr (F16) fp16_saturate();
-    float amax = 0.f;                         // F16: largest magnitude this thread has turned into an fp16 pair
+    RangeWatch amax;                         // F16: largest magnitude this thread has turned into an fp16 pair
     constexpr int TN = BN / 64;               // 32-column MFMA tiles per wave (2 x 2 waves)
     constexpr int NB = (BN * 6 + 255) / 256;  // 16-byte weight pieces per thread and step
 
@@ -833,7 +833,9 @@ __global__ void pack_convT_dgrad_kernel(const float* __restrict__ w, int cin, in
 __device__ __forceinline__ void store_split_element(unsigned short* out, int64_t i, float v, int f16, unsigned* range_flag) {
     unsigned short* o = out + (i >> 9) * 1536 + (i & 511);
     if (f16) {
-        raise_range_flag(range_flag, __builtin_fabsf(v));   // a weight beyond fp16's range is clipped like any operand
+        RangeWatch w;                                       // a weight beyond fp16's range (or not a number) is reported like any operand
+        watch2(w, f32x2{v, v});
+        raise_range_flag(range_flag, w);
         const _Float16 h = static_cast<_Float16>(v);
         const _Float16 l = static_cast<_Float16>((v - static_cast<float>(h)) * kLoScale);
         o[0] = __builtin_bit_cast(unsigned short, h);

@@ -255,7 +255,7 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst) 
     *reinterpret_cast<u32x2*>(dst + 2 * XPLANE) = lo;
 }
 
-__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, float& amax) {
+__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, ddpm::conv::RangeWatch& amax) {
     unsigned h0, l0, h1, l1;
     ddpm::conv::watch2(amax, f32x2{v[0], v[1]});
     ddpm::conv::watch2(amax, f32x2{v[2], v[3]});
@@ -278,7 +278,7 @@ template <int MODE, int PAIR, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams p) {
     static_assert(PAIR == 0 || MODE == WG_CONV3, "two taps per tile exist for the 3x3 convolution only");
     if constexpr (F16) ddpm::conv::fp16_saturate();
-    float amax = 0.f;                     // F16: largest magnitude this thread has turned into an fp16 pair
+    ddpm::conv::RangeWatch amax;                     // F16: largest magnitude this thread has turned into an fp16 pair
     constexpr int BT = 128;
     constexpr int NPL = F16 ? 2 : 3;      // operand planes
     constexpr int F4R = BT / 4;           // float4 per tile row

@@ -143,8 +143,8 @@ class UNetEngine(TrainMixin):
         return self.math or conv_math()
 
     def range_watching(self):
-        """True while this network computes with fp16 pairs, whose operands are clipped beyond +-65504: the kernels
-        raise a device flag when that happens and the host mirror reacts (DDPM_RANGE_WATCH=0 switches the reaction
+        """True while this network computes with fp16 pairs, whose operands are clipped beyond +-65504 and whose matrix
+        instructions do not hand NaNs on: the kernels raise a device flag when they meet either and the host mirror reacts (DDPM_RANGE_WATCH=0 switches the reaction
         off: results are then clipped silently, as a diagnostic). Not while a HIP graph is being captured: the flag's
         read-back and the event query are not capturable, so a replayed graph runs without the watch."""
         return (self.effective_math() == "f16x2" and os.environ.get("DDPM_RANGE_WATCH", "1") != "0"
@@ -191,9 +191,10 @@ class UNetEngine(TrainMixin):
     def range_fallback(self, where):
         self.math = "bf16x3"
         self.range_fallbacks += 1
-        warnings.warn(f"diffusion_model_amd: {where} met activations, weights or gradients beyond +-65504, which the default "
-                      "fp16-pair arithmetic clips; this network now computes with three bf16 planes per operand (full fp32 "
-                      "range, about 1.5x slower). Set DDPM_CONV_MATH=bf16x3 to start there.", RuntimeWarning, stacklevel=3)
+        warnings.warn(f"diffusion_model_amd: {where} met activations, weights or gradients beyond +-65504 (or infinite, or NaN), "
+                      "which the default fp16-pair arithmetic clips; this network now computes with three bf16 planes per operand "
+                      "(full fp32 range and NaN propagation, about 1.5x slower). Set DDPM_CONV_MATH=bf16x3 to start there.",
+                      RuntimeWarning, stacklevel=3)
 
     def _poll_labels(self):
         """Deferred label checks of earlier training steps whose verdict has arrived (never waits)."""
@@ -212,6 +213,8 @@ class UNetEngine(TrainMixin):
             self._poll_labels()
         if self.range_watching():
             self.range_poll()
+            if self._range_pending is None:
+                self.range_clear()     # the flag is one word per GPU: whatever other work raised it is not this call's
         with self.math_scope():
             out = self._run(x, t, y, training)
         if self.range_watching() and not (torch.is_grad_enabled() and training):

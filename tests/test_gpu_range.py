@@ -122,6 +122,55 @@ def test_every_pair_forming_kernel_raises_the_flag():
         assert read_flag() == want, ("pack", bad)
 
 
+@pair_default
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), float("-inf")])
+@pytest.mark.parametrize("cout", [64, 32])
+def test_nan_and_infinite_operands_raise_the_flag_and_propagate_on_three_planes(bad, cout):
+    """fp32 arithmetic hands a NaN or an infinity on to everything it touches (the reference's loss turns NaN, which is
+    how a broken input shows). The fp16 matrix instruction of a wave that saturates its conversions does NOT: a NaN
+    operand comes out as finite numbers. So such an operand must raise the flag like one beyond the range, and the
+    arithmetic the caller then repeats the work in must propagate it exactly where fp32 does."""
+    B, ci, H, W = 2, 32, 12, 12
+    x, w = rnd((B, ci, H, W), 41), rnd((cout, ci, 3, 3), 42, 0.1)
+    xb = x.clone()
+    xb[1, 7, 4, 5] = bad
+    read_flag()
+    conv3x3(xb, w, cout)
+    assert read_flag() == 1, "a NaN / infinite operand must raise the flag"
+    with math_scope("bf16x3"):
+        got = conv3x3(xb, w, cout)
+    # fp32 on the CPU: not finite in the 3x3 neighbourhood, all channels (NaN for a NaN; +-inf for an infinity, which
+    # the three planes turn into NaN, inf = inf + (inf - inf): not finite either way, which is what a caller tests)
+    want = F.conv2d(xb, w, padding=1)
+    assert torch.equal(~torch.isfinite(got.cpu()), ~torch.isfinite(want)) and (~torch.isfinite(want)).sum().item() == 9 * cout
+    if bad != bad:
+        assert torch.equal(torch.isnan(got.cpu()), torch.isnan(want))
+    ok = torch.isfinite(want)
+    assert_close(got.cpu()[ok], F.conv2d(x.double(), w.double(), padding=1)[ok], TOL, "elements the bad operand does not reach")
+
+
+@pair_default
+def test_sample_of_a_nan_input_returns_nan_as_the_reference_does():
+    """x_T with one NaN pixel: the reference's trajectory is NaN from the first step on (train-free eval BatchNorm does
+    not mix samples, so only that sample). The fp16 pair would return finite numbers for it; sample() must not."""
+    T, shape = 10, (2, 1, 28, 28)
+    m, sd = tiny(2, 2)
+    m.eval()
+    dm = pkg.make_diffusion_class(2)(m, pkg.BetaScheduler(T, device="cuda").get_schedule("linear"), T)
+    xT = seeded_tensor(shape, 5, "xT")
+    xT[1, 0, 10, 10] = float("nan")
+    zs = [seeded_tensor(shape, 5, f"z{i}") for i in range(T - 1)]
+    want = oracle_sample(sd, 2, T, xT, zs)
+    with pytest.warns(RuntimeWarning, match="beyond"):
+        with torch.no_grad():
+            got = dm.sample(shape, "cuda", noise=(xT, zs))
+    for a, b in zip(got, want):
+        bn = torch.as_tensor(b[0])
+        assert torch.equal(torch.isnan(a[0]), torch.isnan(bn)), f"NaN pattern at t={a[1]}"
+        assert torch.isnan(bn[1]).any() and not torch.isnan(bn[0]).any()
+        assert_close(a[0][0], bn[0], 2e-4, f"the clean sample at t={a[1]}")
+
+
 def tiny(variant, seed):
     U = pkg.make_unet_class(variant)
     m = U(1, 1, 8, 16)
