@@ -1088,7 +1088,7 @@ int launch_dq(const AttnParams& p, int batch, hipStream_t s) {
 extern "C" int ddpm_attention_fwd(const float* qkv, const float* x, int ldx, const float* gamma, float* out, int ldo,
                                   float* attn_raw, float* lse, const float* temb, int batch, int n, int c, int dq,
                                   void* stream) {
-    DDPM_REQUIRE(qkv && x && gamma && out && batch > 0 && batch <= 65535 && n > 0 && c > 0);
+    DDPM_REQUIRE(qkv && x && gamma && out && batch > 0 && n > 0 && c > 0);
     DDPM_REQUIRE((c & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && ldx >= c && ldo >= c);
     DDPM_REQUIRE(dq == 8 || dq == 16 || dq == 32 || dq == 64 || dq == 128);
     DDPM_REQUIRE(ddpm::aligned16(qkv) && ddpm::aligned16(x) && ddpm::aligned16(out));
@@ -1112,11 +1112,27 @@ extern "C" int ddpm_attention_fwd(const float* qkv, const float* x, int ldx, con
     hipStream_t s = ddpm::as_stream(stream);
     if (ddpm::small_attention() && ddpm::attention_small_fwd_fits(n, c, dq))
         return ddpm::attention_small_fwd(qkv, x, ldx, gamma, temb, out, ldo, attn_raw, lse, batch, n, c, dq, s);
-    switch (dq) {
-        case 8: return launch_dq<8>(p, batch, s);
-        case 16: return launch_dq<16>(p, batch, s);
-        case 32: return launch_dq<32>(p, batch, s);
-        case 64: return launch_dq<64>(p, batch, s);
-        default: return launch_dq<128>(p, batch, s);
+    // the sample index is the grid's z axis (at most 65535): a larger batch runs as consecutive launches over its parts
+    constexpr int kMaxZ = 65535;
+    for (int b0 = 0; b0 < batch; b0 += kMaxZ) {
+        const int nb = batch - b0 < kMaxZ ? batch - b0 : kMaxZ;
+        const int64_t r0 = static_cast<int64_t>(b0) * n;
+        AttnParams q = p;
+        q.qkv = p.qkv + r0 * p.lq;
+        q.x = p.x + r0 * ldx;
+        q.out = p.out + r0 * ldo;
+        if (p.attn_raw) q.attn_raw = p.attn_raw + r0 * c;
+        if (p.lse) q.lse = p.lse + r0;
+        if (p.temb) q.temb = p.temb + static_cast<int64_t>(b0) * c;
+        int rc;
+        switch (dq) {
+            case 8: rc = launch_dq<8>(q, nb, s); break;
+            case 16: rc = launch_dq<16>(q, nb, s); break;
+            case 32: rc = launch_dq<32>(q, nb, s); break;
+            case 64: rc = launch_dq<64>(q, nb, s); break;
+            default: rc = launch_dq<128>(q, nb, s); break;
+        }
+        if (rc) return rc;
     }
+    return DDPM_OK;
 }

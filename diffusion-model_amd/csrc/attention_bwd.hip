@@ -1416,7 +1416,7 @@ extern "C" int ddpm_attention_bwd(const float* qkv, const float* dy, int ldd, co
                                   double* workspace, float* e_scratch, float* dqkv, float* dgamma, int batch, int n, int c, int dq,
                                   void* stream) {
     DDPM_REQUIRE(qkv && dy && attn_raw && lse && gamma && workspace && e_scratch && dqkv && dgamma);
-    DDPM_REQUIRE(batch > 0 && batch <= 65535 && n > 0 && c > 0 && (c & 3) == 0 && c <= 1024 && (ldd & 3) == 0 && ldd >= c);
+    DDPM_REQUIRE(batch > 0 && n > 0 && c > 0 && (c & 3) == 0 && c <= 1024 && (ldd & 3) == 0 && ldd >= c);
     DDPM_REQUIRE(dq == 8 || dq == 16 || dq == 32 || dq == 64 || dq == 128);
     DDPM_REQUIRE(ddpm::aligned16(qkv) && ddpm::aligned16(dy) && ddpm::aligned16(attn_raw) && ddpm::aligned16(dqkv));
     hipStream_t s = ddpm::as_stream(stream);
@@ -1441,14 +1441,30 @@ extern "C" int ddpm_attention_bwd(const float* qkv, const float* dy, int ldd, co
     p.lq = 2 * dq + c;
     p.ldd = ldd;
     p.range_flag = ddpm::f16_math() ? ddpm::range_flag() : nullptr;
-    if (c == 64 && dq == 8) return launch_bwd_fast<8, 64>(p, batch, s);
-    if (c == 128 && dq == 16) return launch_bwd_fast<16, 128>(p, batch, s);
-    if (c == 256 && dq == 32 && ddpm::split_math()) return launch_bwd_x3<32, 256>(p, batch, s);
-    switch (dq) {
-        case 8: return launch_bwd<8>(p, batch, s);
-        case 16: return launch_bwd<16>(p, batch, s);
-        case 32: return launch_bwd<32>(p, batch, s);
-        case 64: return launch_bwd<64>(p, batch, s);
-        default: return launch_bwd<128>(p, batch, s);
+    // the sample index is the grid's z axis (at most 65535): a larger batch runs as consecutive launches over its parts
+    constexpr int kMaxZ = 65535;
+    for (int b0 = 0; b0 < batch; b0 += kMaxZ) {
+        const int nb = batch - b0 < kMaxZ ? batch - b0 : kMaxZ;
+        const int64_t r0 = static_cast<int64_t>(b0) * n;
+        BwdParams q = p;
+        q.qkv = p.qkv + r0 * p.lq;
+        q.dy = p.dy + r0 * ldd;
+        q.o = p.o + r0 * c;
+        q.lse = p.lse + r0;
+        q.e = p.e + r0;
+        q.dqkv = p.dqkv + r0 * p.lq;
+        int rc;
+        if (c == 64 && dq == 8) rc = launch_bwd_fast<8, 64>(q, nb, s);
+        else if (c == 128 && dq == 16) rc = launch_bwd_fast<16, 128>(q, nb, s);
+        else if (c == 256 && dq == 32 && ddpm::split_math()) rc = launch_bwd_x3<32, 256>(q, nb, s);
+        else switch (dq) {
+            case 8: rc = launch_bwd<8>(q, nb, s); break;
+            case 16: rc = launch_bwd<16>(q, nb, s); break;
+            case 32: rc = launch_bwd<32>(q, nb, s); break;
+            case 64: rc = launch_bwd<64>(q, nb, s); break;
+            default: rc = launch_bwd<128>(q, nb, s); break;
+        }
+        if (rc) return rc;
     }
+    return DDPM_OK;
 }

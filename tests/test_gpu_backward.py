@@ -337,3 +337,33 @@ def test_attention_bwd_very_negative_scores_ragged(case):
     assert_close(got[..., :dq], q.grad, TOL, f"dq {case}")
     assert_close(got[..., dq:2 * dq], k.grad, TOL, f"dk {case}")
     assert_close(got[..., 2 * dq:], v.grad, TOL, f"dv {case}")
+
+
+def test_attention_batch_beyond_the_grid_limit():
+    """The sample index is the launch grid's z axis, which holds 65535: a larger batch (the reference's classes take any
+    batch, second-iteration/unet.py:52-66) runs as consecutive launches and must give, for the samples on either side of
+    the cut, the bits the same samples give alone."""
+    B, N, c, dq = 65535 + 9, 64, 64, 8
+    g = torch.Generator(device="cuda").manual_seed(3)
+    qkv = torch.randn((B, N, 2 * dq + c), device="cuda", generator=g) * 0.3
+    x = torch.randn((B, N, c), device="cuda", generator=g)
+    dy = torch.randn((B, N, c), device="cuda", generator=g)
+    gd, temb = torch.tensor([0.6], device="cuda"), torch.randn((B, c), device="cuda", generator=g)
+
+    def run(lo, hi):
+        b = hi - lo
+        q, xx, dd, te = qkv[lo:hi].contiguous(), x[lo:hi].contiguous(), dy[lo:hi].contiguous(), temb[lo:hi].contiguous()
+        out, raw, lse = torch.empty((b, N, c), device="cuda"), torch.empty((b, N, c), device="cuda"), torch.empty((b, N), device="cuda")
+        call("ddpm_attention_fwd", P(q), P(xx), c, P(gd), P(out), c, P(raw), P(lse), P(te), b, N, c, dq, stream())
+        dqkv = torch.full((b, N, 2 * dq + c), float("nan"), device="cuda")
+        dgamma = torch.empty(1, device="cuda")
+        ws, es = torch.empty(4096, dtype=torch.float64, device="cuda"), torch.empty((b, N), device="cuda")
+        call("ddpm_attention_bwd", P(q), P(dd), c, P(raw), P(lse), P(gd), P(ws), P(es), P(dqkv), P(dgamma), b, N, c, dq, stream())
+        torch.cuda.synchronize()
+        return out, lse, dqkv
+
+    out, lse, dqkv = run(0, B)
+    assert torch.isfinite(out).all() and torch.isfinite(dqkv).all()
+    lo = 65535 - 6
+    o2, l2, d2 = run(lo, B)                      # the 15 samples around the cut, as a batch of their own
+    assert torch.equal(out[lo:], o2) and torch.equal(lse[lo:], l2) and torch.equal(dqkv[lo:], d2)
