@@ -67,6 +67,7 @@ _SIGNATURES = {
     "ddpm_bn_stats_noalloc_max_channels": [],
     "ddpm_bn_stats_noalloc": [P, I32, I64, I32, F32, F32, P, P, P, P, P],
     "ddpm_bn_partial_sums": [P, I32, I64, I32, P, P, P],
+    "ddpm_bn_sums_from_partials": [P, I32, I32, P, P],
     "ddpm_bn_finalize_stats": [P, I64, I32, F32, F32, P, P, P, P, P],
     "ddpm_bn_bwd_sums": [P, I32, P, I32, P, I32, P, P, P, P, I32, I64, I32, P, P, P],
     "ddpm_bn_bwd_apply": [P, I32, P, I32, P, I32, P, P, P, P, P, I64, I32, I64, I32, P, P, I32, P, I32, P, P],

@@ -568,6 +568,14 @@ extern "C" int ddpm_bn_partial_sums(const float* x, int ldx, int64_t rows, int c
     return ddpm::check_launch("bn_partial_sums");
 }
 
+// The partial sums a producer left (ddpm_conv3x3_fwd_stats, ddpm_bn_partials) finished to this rank's raw sums: the
+// second half of ddpm_bn_partial_sums alone.
+extern "C" int ddpm_bn_sums_from_partials(const double* partial, int nblocks, int c, double* sums, void* stream) {
+    DDPM_REQUIRE(partial && sums && nblocks > 0 && c > 0 && (c & 3) == 0 && c <= 1024);
+    pair_sums_final_kernel<<<(c + kFin - 1) / kFin, kThreads, 0, as_stream(stream)>>>(partial, nblocks, c, sums);
+    return ddpm::check_launch("pair_sums_final_kernel");
+}
+
 extern "C" int ddpm_bn_finalize_stats(const double* sums, int64_t total_rows, int c, float eps, float momentum, float* mean, float* invstd,
                                       float* running_mean, float* running_var, void* stream) {
     DDPM_REQUIRE(sums && mean && invstd && total_rows > 0 && c > 0);

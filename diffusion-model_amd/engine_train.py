@@ -110,7 +110,7 @@ class TrainMixin:
         invstd = torch.empty(cout, device=dev, dtype=torch.float32)
         stat_rows = b * h * w
         global_stats = self.sync_bn and _dist_active()
-        fused = self._fused_stats and first is None and not global_stats
+        fused = self._fused_stats and first is None
         if first is not None:
             ep = Epilogue(None, _ptr(bias), None, None)
             call("ddpm_conv3x3_first_fwd", _ptr(first), _ptr(self.T(conv_key + ".weight")), C.byref(ep), ACT_NONE, raw.ptr, b,
@@ -118,18 +118,22 @@ class TrainMixin:
         elif fused:
             # the convolution's epilogue leaves the partial sums of the batch statistics: no separate pass over `raw`
             nblk = self.conv3x3_stats(src, self.packed_conv3(conv_key), cout, raw, bias, self._workspace(dev))
-            call("ddpm_bn_stats_from_partials", _ptr(self._workspace(dev)), nblk, stat_rows, cout, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
-                 _ptr(self.T(bn_key + ".running_mean")), _ptr(self.T(bn_key + ".running_var")), _stream())
+            if not global_stats:
+                call("ddpm_bn_stats_from_partials", _ptr(self._workspace(dev)), nblk, stat_rows, cout, BN_EPS, BN_MOMENTUM, _ptr(mean),
+                     _ptr(invstd), _ptr(self.T(bn_key + ".running_mean")), _ptr(self.T(bn_key + ".running_var")), _stream())
         else:
             self.conv3x3(src, self.packed_conv3(conv_key), cout, raw, None, bias)
-        if fused:
+        if fused and not global_stats:
             pass
         elif global_stats:
             # global-batch statistics: this rank's sums are all-reduced, then finalised on every rank. Every rank
             # holds the same number of samples (the batch axis is cut evenly), so the global row count needs no exchange.
             from . import parallel
             sums = torch.empty(2 * cout, device=dev, dtype=torch.float64)
-            call("ddpm_bn_partial_sums", raw.ptr, raw.ld, stat_rows, cout, _ptr(self._workspace(dev)), _ptr(sums), _stream())
+            if fused:
+                call("ddpm_bn_sums_from_partials", _ptr(self._workspace(dev)), nblk, cout, _ptr(sums), _stream())
+            else:
+                call("ddpm_bn_partial_sums", raw.ptr, raw.ld, stat_rows, cout, _ptr(self._workspace(dev)), _ptr(sums), _stream())
             parallel.all_reduce_(sums, group=self.dist_group)
             stat_rows = stat_rows * parallel.world_size(self.dist_group)
             call("ddpm_bn_finalize_stats", _ptr(sums), stat_rows, cout, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),

@@ -405,6 +405,11 @@ int ddpm_bn_bwd(const float* x, int ldx, const float* dout, int ldd, const float
  * With one rank the two halves compute exactly what ddpm_bn_stats / ddpm_bn_bwd compute. */
 int ddpm_bn_partial_sums(const float* x, int ldx, int64_t rows, int c, double* workspace, double* sums,
                          void* stream);
+/* This rank's raw float64 sums (sum x | sum x^2, 2*c doubles) from partial sums that a producer left behind
+ * (ddpm_conv3x3_fwd_stats, ddpm_bn_partials): the second half of ddpm_bn_partial_sums, for data-parallel training
+ * with global-batch statistics when the convolution's epilogue has already summed its output. Same layer as above:
+ * second-iteration/unet.py:17 at the global batch. */
+int ddpm_bn_sums_from_partials(const double* partial, int nblocks, int c, double* sums, void* stream);
 int ddpm_bn_finalize_stats(const double* sums, int64_t total_rows, int c, float eps, float momentum,
                            float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
 int ddpm_bn_bwd_sums(const float* x, int ldx, const float* dout, int ldd, const float* residual, int ldr,

@@ -4,7 +4,9 @@ collectives through the host; the GPU work is the real HIP path). Checks, agains
   2. the bucketed averager (recording step, then buckets from inside the backward) == the flat all-reduce;
   3. 10 Adam steps sharded 2 + 2 reproduce the reference's single-process loss trace (batch 4);
   4. sharded sampling with sliced injected noise == unsharded sampling, bit for bit;
-  5. ranks that were seeded alike still draw different noise on the GPU (torch's generators and the in-kernel stream).
+  5. ranks that were seeded alike still draw different noise on the GPU (torch's generators and the in-kernel stream);
+  6. global-batch BatchNorm refuses shards of different sizes;
+  7. a full-width network cut 2 + 2 with global-batch BatchNorm == one process on the whole batch (loss, gradients, running statistics).
 Prints DP_WORKER_OK on rank 0."""
 import os
 import sys
@@ -164,6 +166,35 @@ def main():
         raise AssertionError("uneven shards were accepted")
     except ValueError as e:
         assert "same number of samples" in str(e), e
+
+    # ---- 7: full-width network (the halo kernel's epilogue statistics feed the all-reduced sums) -------------------
+    # two ranks with global-batch BatchNorm against ONE process on the whole batch, both on the HIP path
+    U = pkg.make_unet_class(2)
+    wide = U(1, 1, 64, 128)
+    wide.load_state_dict(seeded_state_dict(wide.state_dict(), 8))
+    wide = wide.cuda().train()
+    xb, tb = seeded_tensor((4, 1, 28, 28), 70, "x"), seeded_ints((4,), 1000, 70, "t")
+    tg = seeded_tensor((4, 1, 28, 28), 71, "tgt")
+    sd0 = {k: v.clone() for k, v in wide.state_dict().items()}
+    whole_loss = torch.nn.MSELoss()(wide(xb.cuda(), tb.cuda()), tg.cuda())
+    whole_loss.backward()
+    whole = {k: p.grad.clone() for k, p in wide.named_parameters()}
+    whole_stats = {k: v.clone() for k, v in wide.state_dict().items() if "running_" in k}
+    wide.load_state_dict(sd0)
+    wide.zero_grad()
+    wide._engine.sync_bn = True
+    lo, hi = parallel.shard_range(4, world, rank)
+    loss = torch.nn.MSELoss()(wide(xb[lo:hi].cuda(), tb[lo:hi].cuda()), tg[lo:hi].cuda())
+    loss.backward()
+    parallel.average_gradients(list(wide.parameters()))
+    assert abs(mean_over_ranks(loss.item()) - whole_loss.item()) <= 1e-5 * abs(whole_loss.item())
+    # (+ 1e-6: the biases in front of a BatchNorm have gradients that are zero up to rounding noise)
+    worst = sorted(((p.grad - whole[k]).abs().max().item() / (2e-4 * whole[k].abs().max().item() + 1e-6), k)
+                   for k, p in wide.named_parameters())[::-1]
+    assert worst[0][0] <= 1.0, ("full-width sync-BN against one process", worst[:5])
+    for k, v in wide.state_dict().items():
+        if "running_" in k:
+            assert (v - whole_stats[k]).abs().max().item() <= 1e-6 * max(1.0, whole_stats[k].abs().max().item()), k
 
     dist.barrier()
     if rank == 0:
