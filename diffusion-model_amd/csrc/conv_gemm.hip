@@ -334,6 +334,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * XROW];
     __shared__ int4 rowinfo[BM];
+    // transposed conv: byte offset of every row's output pixel (2y + off_y, 2x + off_x) from the tile's first one, with
+    // the four taps' validity in its low four bits (a pixel's stride is a multiple of 16 bytes)
+    __shared__ __attribute__((aligned(16))) unsigned rowout[MODE == MODE_CONVT ? BM : 4];
 
     const int nwg = gridDim.x;
     int id = blockIdx.x;
@@ -392,6 +395,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
             rowinfo[tid] = info;
         }
         __syncthreads();
+        long long convt_ref = 0;   // MODE_CONVT: output pixel index behind offset 0 of rowout (the tile's first row, tap 0)
+        if (MODE == MODE_CONVT) {
+            const int4 first = rowinfo[0];
+            convt_ref = (static_cast<long long>(__builtin_amdgcn_readfirstlane(first.y)) * p.out_h + 2 * __builtin_amdgcn_readfirstlane(first.z) + p.off_y) * p.out_w +
+                        2 * __builtin_amdgcn_readfirstlane(first.w) + p.off_x;
+            if (tid < BM) {
+                const int4 info = rowinfo[tid];
+                unsigned packed = 0u;
+                if (info.x >= 0) {
+                    const int oy0 = 2 * info.z + p.off_y, ox0 = 2 * info.w + p.off_x;
+                    const long long pix = (static_cast<long long>(info.y) * p.out_h + oy0) * p.out_w + ox0;
+                    unsigned mask = 0u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int oy = oy0 + (q >> 1), ox = ox0 + (q & 1);
+                        if (oy >= 0 && oy < p.out_h && ox >= 0 && ox < p.out_w) mask |= 1u << q;
+                    }
+                    packed = static_cast<unsigned>((pix - convt_ref) * p.ldo * 4ll) | mask;
+                }
+                rowout[tid] = packed;
+            }
+            __syncthreads();
+        }
 
         int4 ri[2];
 #pragma unroll
@@ -625,6 +651,49 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3_kernel(const GemmParams p
                     for (int e = 0; e < 16; ++e) {
                         const unsigned rel = static_cast<unsigned>(i * 64 + (e & 3) + 8 * (e >> 2));
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, vo + rel * ldo4, 0, DDPM_STORE_AUX);
+                    }
+                }
+            }
+            continue;
+        }
+        if (MODE == MODE_CONVT && (p.cout & 31) == 0) {
+            // every column block lies inside one tap (cout is a multiple of 32): a row's output offset comes from the
+            // tile's table, the tap and the channel add a per-block constant, and a tap that falls outside the cropped
+            // image turns the offset into one the descriptor's range check drops. Same values as the general path below.
+            const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out + convt_ref * p.ldo, 0x7fffffffll);
+            unsigned tapoff[TN];
+            float scj[TN], shj[TN];
+            int qj[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int n = n0 + (wn * TN + j) * 32 + r;
+                asm volatile("" : "+v"(n));
+                const int q = n / p.cout, co = n - q * p.cout;
+                qj[j] = n < p.n_total ? q : -1;      // -1: no such column, every store of the block is dropped
+                tapoff[j] = static_cast<unsigned>(((q >> 1) * p.out_w + (q & 1)) * p.ldo + co) * 4u;
+                scj[j] = (p.scale && n < p.n_total) ? p.scale[co] : 1.0f;
+                shj[j] = (p.shift && n < p.n_total) ? p.shift[co] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i >= my_slots) continue;
+                unsigned ro[16];
+#pragma unroll
+                for (int eq = 0; eq < 4; ++eq) {
+                    const uint4 t4 = *reinterpret_cast<const uint4*>(&rowout[(i * 2 + wm) * 32 + 8 * eq + 4 * h]);
+                    ro[eq * 4 + 0] = t4.x;
+                    ro[eq * 4 + 1] = t4.y;
+                    ro[eq * 4 + 2] = t4.z;
+                    ro[eq * 4 + 3] = t4.w;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float v = master[i][j][e] * scj[j] + shj[j];
+                        const bool ok = qj[j] >= 0 && ((ro[e] >> (qj[j] & 3)) & 1u);
+                        const unsigned off = ok ? (ro[e] & ~15u) + tapoff[j] : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, off, 0, DDPM_STORE_AUX);
                     }
                 }
             }

@@ -276,7 +276,11 @@ def test_conv1x1_many_rows(case):
 
 
 @pytest.mark.parametrize("case", [(2, 7, 7, 64, 32, 14, 14), (2, 7, 7, 32, 16, 15, 15), (2, 16, 16, 32, 16, 16, 16),
-                                  (1, 14, 14, 128, 64, 28, 28), (3, 15, 15, 8, 4, 15, 15), (2, 7, 5, 16, 8, 17, 9)])
+                                  (1, 14, 14, 128, 64, 28, 28), (3, 15, 15, 8, 4, 15, 15), (2, 7, 5, 16, 8, 17, 9),
+                                  # output channels in whole 32-column blocks (the table-driven scatter): padded, cropped to
+                                  # half (the reference's third up block), cropped by odd amounts, ragged last tile
+                                  (2, 7, 7, 64, 32, 15, 15), (2, 16, 16, 32, 64, 16, 16), (2, 7, 5, 16, 32, 17, 9),
+                                  (1, 9, 9, 32, 32, 13, 15), (5, 11, 13, 64, 96, 19, 23), (3, 32, 32, 128, 64, 32, 32)])
 def test_convT2x2_pad_crop(case):
     B, H, W, ci, co, OH, OW = case
     x, w, b = rnd((B, ci, H, W), 1), rnd((ci, co, 2, 2), 2, ci ** -0.5), rnd((co,), 3)
