@@ -265,13 +265,15 @@ __device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4
 }
 
 // (the same with the range watch of conv_common.h: for q, k and v, which come from memory; probabilities need none)
-__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, ddpm::conv::RangeWatch& amax) {
+template <class W>
+__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, W& amax) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[2 * e], v[2 * e + 1]});
     split8_f16(v, hi, lo);
 }
 
-__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, int plane_stride, ddpm::conv::RangeWatch& amax) {
+template <class W>
+__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, int plane_stride, W& amax) {
     unsigned h0, l0, h1, l1;
     ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[0], v[1]});
     ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[2], v[3]});
@@ -298,11 +300,18 @@ using ddpm::conv::mfma16;
 #ifndef DDPM_ATTN_ABLATE
 #define DDPM_ATTN_ABLATE 0   // diagnostic builds only (wrong results): bit 0 no softmax arithmetic, bit 1 no value-product MFMAs, bit 2 no staging in the loop, bit 3 no transposed V reads in the loop; pipelined kernel: bit 4 no softmax slices, bit 5 no staging, bit 6 V fragments of the first pair only, bit 7 no barrier in the loop
 #endif
-template <int DQ, int QB, int NCT, bool F16>
-__global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnParams p) {
+// KVW: this workgroup watches the range of the K and V tiles it stages (the first query block of a sample does it for
+// all of them: they stage the same tiles); each watches its own queries. The tile buffers are the caller's, so that
+// the two instantiations inside one kernel share them.
+template <int DQ, int QB, int NCT, bool F16, bool KVW>
+__device__ __forceinline__ void attention_fwd_x3_body(const AttnParams& p, const dim3 bid, unsigned char* sK_mem, unsigned char* sV_mem) {
     if constexpr (F16) ddpm::conv::fp16_saturate();
-    ddpm::conv::RangeWatch amax;                           // F16: largest magnitude of q, k, v this thread has turned into an fp16 pair
-    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
+    ddpm::conv::RangeWatch amax;                           // F16: largest magnitude of q this thread has turned into an fp16 pair
+    ddpm::conv::NoWatch unwatched_kv;
+    auto& kvw = [&]() -> auto& {   // k and v: watched by `amax` too, or not at all
+        if constexpr (KVW) return amax;
+        else return unwatched_kv;
+    }();
     constexpr int NPL = F16 ? 2 : 3;            // operand planes
     constexpr int CS = 32 * NCT;
     constexpr int KD = DQ < 16 ? 16 : DQ;       // K/Q depth padded to the MFMA's 16
@@ -316,8 +325,8 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
     constexpr int KPT = (KF4 + 255) / 256, VPT = VF4 / 256;
     static_assert(VF4 % 256 == 0, "V tile must split evenly over 256 threads");
 
-    __shared__ __attribute__((aligned(16))) unsigned char sK[2][KT * KROW];
-    __shared__ __attribute__((aligned(16))) unsigned char sV[2][NPL * VPLANE];
+    unsigned char (*sK)[KT * KROW] = reinterpret_cast<unsigned char (*)[KT * KROW]>(sK_mem);        // [2]
+    unsigned char (*sV)[NPL * VPLANE] = reinterpret_cast<unsigned char (*)[NPL * VPLANE]>(sV_mem);  // [2]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
             const int f = tid + 256 * i;
             const int row = f / (DQ / 4), c4 = f % (DQ / 4);
             if (f < KF4) {
-                if constexpr (F16) split4_store_f16(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL, amax);
+                if constexpr (F16) split4_store_f16(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL, kvw);
                 else split4_store(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL);
             }
         }
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
         for (int i = 0; i < VPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CS / 4), c4 = f % (CS / 4);
-            if constexpr (F16) split4_store_f16(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE, amax);
+            if constexpr (F16) split4_store_f16(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE, kvw);
             else split4_store(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE);
         }
     };
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
         __syncthreads();
     }
 
-    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, amax);
+    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, ddpm::conv::merged(amax, kvw));
     if (!wave_active) return;
     if constexpr (F16) {
 #pragma unroll
@@ -604,6 +613,17 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
     }
 }
 
+template <int DQ, int QB, int NCT, bool F16>
+__global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnParams p) {
+    constexpr int NPL = F16 ? 2 : 3, KD = DQ < 16 ? 16 : DQ;
+    constexpr int KROW = NPL * KD * 2 + 16, VPLANE = KT * (32 * NCT * 2 + 64);   // as in the body
+    __shared__ __attribute__((aligned(16))) unsigned char sK[2 * KT * KROW];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[2 * NPL * VPLANE];
+    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
+    if (F16 && bid.x == 0) attention_fwd_x3_body<DQ, QB, NCT, F16, true>(p, bid, sK, sV);
+    else attention_fwd_x3_body<DQ, QB, NCT, F16, false>(p, bid, sK, sV);
+}
+
 // Software-pipelined version of the kernel above (one 32-query block per wave). A wave of the kernel above goes
 // through its tile in phases -- scores (MFMA), softmax and splitting (VALU), value product (MFMA), staging of the
 // next tile (VALU) -- and the two waves that share a SIMD fall into step with each other, so that the matrix pipe
@@ -613,11 +633,17 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
 // probabilities, and the splitting + LDS stores of the tiles being staged. A VALU instruction issues while the MFMA
 // in front of it executes, so the wave keeps both pipes busy by itself. Same operations on the same values in the
 // same order per query as the kernel above: the results are bit-identical.
-template <int DQ, int NCT, int NW, bool F16>
-__global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const AttnParams p) {
+// KVW: this workgroup watches the range of the K and V tiles it stages. Every query block of a sample stages the same
+// K and V, so one of them (the first) does the checking for all; each checks its own queries.
+template <int DQ, int NCT, int NW, bool F16, bool KVW>
+__device__ __forceinline__ void attention_fwd_x3p_body(const AttnParams& p, const dim3 bid) {
     if constexpr (F16) ddpm::conv::fp16_saturate();
-    ddpm::conv::RangeWatch amax;                   // F16: largest magnitude of q, k, v this thread has turned into an fp16 pair
-    const dim3 bid = ddpm::xcd_block();
+    ddpm::conv::RangeWatch amax;                   // F16: largest magnitude of q this thread has turned into an fp16 pair
+    ddpm::conv::NoWatch unwatched_kv;
+    auto& kvw = [&]() -> auto& {   // k and v: watched by `amax` too, or not at all
+        if constexpr (KVW) return amax;
+        else return unwatched_kv;
+    }();
     constexpr int NPL = F16 ? 2 : 3;    // operand planes
     constexpr int NPR = F16 ? 3 : 6;    // MFMAs per fragment pair
     constexpr int NT = 64 * NW;
@@ -705,14 +731,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
         const int f = tid + NT * i;
         const int row = f / (DQ / 4), c4 = f % (DQ / 4);
         if (f < KF4) {
-            if constexpr (F16) split4_store_f16(kreg[i], dst + row * KROW + c4 * 8, KPL, amax);
+            if constexpr (F16) split4_store_f16(kreg[i], dst + row * KROW + c4 * 8, KPL, kvw);
             else split4_store(kreg[i], dst + row * KROW + c4 * 8, KPL);
         }
     };
     auto store_v1 = [&](int i, unsigned char* dst) {
         const int f = tid + NT * i;
         const int row = f / (CS / 4), c4 = f % (CS / 4);
-        if constexpr (F16) split4_store_f16(vreg[i], dst + row * VROW + c4 * 8, VPLANE, amax);
+        if constexpr (F16) split4_store_f16(vreg[i], dst + row * VROW + c4 * 8, VPLANE, kvw);
         else split4_store(vreg[i], dst + row * VROW + c4 * 8, VPLANE);
     };
 
@@ -938,7 +964,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
     }
     body(std::false_type{}, tiles - 1);
 
-    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, amax);
+    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, ddpm::conv::merged(amax, kvw));
     if (!wave_active) return;
     if constexpr (F16) {
 #pragma unroll
@@ -969,6 +995,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const Att
             *reinterpret_cast<f32x4*>(p.out + pix * p.ldo + c) = y;
         }
     }
+}
+
+template <int DQ, int NCT, int NW, bool F16>
+__global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const AttnParams p) {
+    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
+    if (F16 && bid.x == 0) attention_fwd_x3p_body<DQ, NCT, NW, F16, true>(p, bid);
+    else attention_fwd_x3p_body<DQ, NCT, NW, F16, false>(p, bid);
 }
 
 template <int DQ, int NCT, int NW, bool F16>

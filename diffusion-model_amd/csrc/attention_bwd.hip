@@ -709,7 +709,8 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst, 
 }
 
 // The same for the fp16 pair: two planes; `amax` is the thread's range watch (conv_common.h).
-__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, ddpm::conv::RangeWatch& amax) {
+template <class W>
+__device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4& lo, W& amax) {
     unsigned hh[4], ll[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -721,7 +722,8 @@ __device__ __forceinline__ void split8_f16(const float (&v)[8], u32x4& hi, u32x4
     lo = u32x4{ll[0], ll[1], ll[2], ll[3]};
 }
 
-__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, int plane_stride, ddpm::conv::RangeWatch& amax) {
+template <class W>
+__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, int plane_stride, W& amax) {
     unsigned h0, l0, h1, l1;
     ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[0], v[1]});
     ddpm::conv::watch2(amax, ddpm::conv::f32x2{v[2], v[3]});
@@ -732,8 +734,8 @@ __device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* d
 }
 
 // 8 floats at p (two float4; zeros when !ok), times `scale` -> the operand's planes (pl[2] unused by the fp16 pair)
-template <bool F16>
-__device__ __forceinline__ void load_split8(const float* p, bool ok, u32x4 (&pl)[F16 ? 2 : 3], float scale, ddpm::conv::RangeWatch& amax) {
+template <bool F16, class W>
+__device__ __forceinline__ void load_split8(const float* p, bool ok, u32x4 (&pl)[F16 ? 2 : 3], float scale, W& amax) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -749,14 +751,14 @@ __device__ __forceinline__ void load_split8(const float* p, bool ok, u32x4 (&pl)
     else split8(v, pl[0], pl[1], pl[2]);
 }
 
-template <bool F16>
-__device__ __forceinline__ void split8_any(const float (&v)[8], u32x4 (&pl)[F16 ? 2 : 3], ddpm::conv::RangeWatch& amax) {
+template <bool F16, class W>
+__device__ __forceinline__ void split8_any(const float (&v)[8], u32x4 (&pl)[F16 ? 2 : 3], W& amax) {
     if constexpr (F16) split8_f16(v, pl[0], pl[1], amax);
     else split8(v, pl[0], pl[1], pl[2]);
 }
 
-template <bool F16>
-__device__ __forceinline__ void split4_store_any(const f32x4 v, unsigned char* dst, int plane_stride, ddpm::conv::RangeWatch& amax) {
+template <bool F16, class W>
+__device__ __forceinline__ void split4_store_any(const f32x4 v, unsigned char* dst, int plane_stride, W& amax) {
     if constexpr (F16) split4_store_f16(v, dst, plane_stride, amax);
     else split4_store(v, dst, plane_stride);
 }
@@ -792,11 +794,17 @@ __device__ __forceinline__ int swz(int row, int ch) { return 256 * row + 16 * (c
 // starting at bid.y * CT (CT <= 128; the dO tile is read transposed and sits in swizzled 256-byte
 // rows). Both at once when the registers allow (C <= 128); wider layers run the two halves as separate
 // launches, each recomputing the scores (depth-DQ products, cheap beside the C-deep ones).
-template <int DQ, int CT, bool DK, bool DV, int WPS = 1, bool F16 = false>
-__global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdParams p) {
+// SW: this workgroup watches the range of the dO and Q tiles that stream past (every key block of a sample stages the
+// same ones: the first does the checking for all); its own K, V and dS it always watches.
+template <int DQ, int CT, bool DK, bool DV, bool F16, int SW>   // SW: 0 = the streamed tiles are not watched, 1 = watched, 2 = watched by `amax` itself
+__device__ __forceinline__ void attn_bwd_dkv_x3_body(const BwdParams& p, const dim3 bid) {
     if constexpr (F16) ddpm::conv::fp16_saturate();
     ddpm::conv::RangeWatch amax;                     // F16: largest magnitude this thread has turned into an fp16 pair
-    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
+    std::conditional_t<SW == 1, ddpm::conv::RangeWatch, ddpm::conv::NoWatch> swatch_own;   // the same for the streamed tiles
+    auto& swatch = [&]() -> auto& {
+        if constexpr (SW == 2) return amax;
+        else return swatch_own;
+    }();
     static_assert(!DV || CT <= 128, "transposed dO reads assume 256-byte rows");
     using PR = Products<F16>;
     constexpr int NPL = F16 ? 2 : 3;
@@ -892,11 +900,11 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
         for (int i = 0; i < DOPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CT / 4), c4 = f % (CT / 4);
-            split4_store_any<F16>(doreg[i] * g, sDO + buf * NPL * DPLANE + dofs(row, c4 >> 1) + 8 * (c4 & 1), DPLANE, amax);
+            split4_store_any<F16>(doreg[i] * g, sDO + buf * NPL * DPLANE + dofs(row, c4 >> 1) + 8 * (c4 & 1), DPLANE, swatch);
         }
         if (tid < QF4) {
             const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
-            split4_store_any<F16>(qreg, sQ + buf * NPL * QPLANE + row * QROW + c4 * 8, QPLANE, amax);
+            split4_store_any<F16>(qreg, sQ + buf * NPL * QPLANE + row * QROW + c4 * 8, QPLANE, swatch);
         }
         if (tid < TQ) {
             sL[buf * TQ + tid] = lreg;
@@ -1073,7 +1081,7 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
         __syncthreads();
     }
 
-    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, k_ok ? ddpm::conv::merged(amax, amax_ds) : amax);
+    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, ddpm::conv::merged(k_ok ? ddpm::conv::merged(amax, amax_ds) : amax, swatch));
     if (!wave_active || !k_ok) return;
     float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + kj) * p.lq;
     if (DV) {
@@ -1100,6 +1108,20 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdPara
     }
 }
 
+template <int DQ, int CT, bool DK, bool DV, int WPS = 1, bool F16 = false>
+__global__ __launch_bounds__(256, WPS) void attn_bwd_dkv_x3_kernel(const BwdParams p) {
+    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
+    // (the dK kernel of 128 channels holds V of all channels in registers and has none to spare for a second copy of
+    // its code: there every block keeps watching what it stages)
+    constexpr bool kTwoBodies = F16 && !(DK && CT > 64);
+    if constexpr (!kTwoBodies) {
+        attn_bwd_dkv_x3_body<DQ, CT, DK, DV, F16, F16 ? 2 : 0>(p, bid);
+    } else {
+        if (bid.x == 0) attn_bwd_dkv_x3_body<DQ, CT, DK, DV, F16, 2>(p, bid);
+        else attn_bwd_dkv_x3_body<DQ, CT, DK, DV, F16, 0>(p, bid);
+    }
+}
+
 template <int DQ, int CT, bool DK, bool DV, bool F16 = false>
 constexpr int dkv_x3_lds() {
     constexpr int KD = DQ < 16 ? 16 : DQ, NPL = F16 ? 2 : 3;
@@ -1107,11 +1129,17 @@ constexpr int dkv_x3_lds() {
 }
 
 // Query-side gradient of 32 queries per wave (dO of all CT = C channels in registers).
-template <int DQ, int CT, bool F16 = false>
-__global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(const BwdParams p) {
+// SW: this workgroup watches the range of the K and V tiles that stream past (as above: the first query block of a sample
+// does it for all); its own Q, dO and dS it always watches.
+template <int DQ, int CT, bool F16, bool SW>
+__device__ __forceinline__ void attn_bwd_dq_x3_body(const BwdParams& p, const dim3 bid) {
     if constexpr (F16) ddpm::conv::fp16_saturate();
     ddpm::conv::RangeWatch amax;                     // F16: largest magnitude this thread has turned into an fp16 pair
-    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
+    ddpm::conv::NoWatch unwatched_stream;
+    auto& swatch = [&]() -> auto& {   // the streamed tiles: watched by `amax` too, or not at all
+        if constexpr (SW) return amax;
+        else return unwatched_stream;
+    }();
     using PR = Products<F16>;
     constexpr int NPL = F16 ? 2 : 3;
     constexpr int KCV = CT / 16;
@@ -1177,13 +1205,13 @@ __global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(
     auto store_tile = [&](int buf) {
         if (tid < KF4) {
             const int row = tid / (DQ / 4), c4 = tid % (DQ / 4);
-            split4_store_any<F16>(kreg, sK + buf * NPL * KPLANE + row * KROW + c4 * 8, KPLANE, amax);
+            split4_store_any<F16>(kreg, sK + buf * NPL * KPLANE + row * KROW + c4 * 8, KPLANE, swatch);
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CT / 4), c4 = f % (CT / 4);
-            split4_store_any<F16>(vreg[i], sV + buf * NPL * VPLANE + row * VROW + c4 * 8, VPLANE, amax);
+            split4_store_any<F16>(vreg[i], sV + buf * NPL * VPLANE + row * VROW + c4 * 8, VPLANE, swatch);
         }
     };
 
@@ -1299,7 +1327,7 @@ __global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(
         if (more) store_tile(buf ^ 1);
         __syncthreads();
     }
-    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, amax);
+    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, ddpm::conv::merged(amax, swatch));
     if (!wave_active || !q_ok) return;
     float* drow = p.dqkv + (static_cast<int64_t>(b) * p.n + qi) * p.lq;
     const f32x16 dq = F16 ? dq2[0] + dq2[1] * kLoInv : dq2[0] + dq2[1];
@@ -1310,6 +1338,13 @@ __global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(
         f32x4 v = {dq[gq * 4], dq[gq * 4 + 1], dq[gq * 4 + 2], dq[gq * 4 + 3]};
         *reinterpret_cast<f32x4*>(drow + d) = v;
     }
+}
+
+template <int DQ, int CT, bool F16 = false>
+__global__ __launch_bounds__(256, CT <= 128 ? 2 : 1) void attn_bwd_dq_x3_kernel(const BwdParams p) {
+    const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
+    if (F16 && bid.x == 0) attn_bwd_dq_x3_body<DQ, CT, F16, F16>(p, bid);
+    else attn_bwd_dq_x3_body<DQ, CT, F16, false>(p, bid);
 }
 
 template <int DQ, int CT, bool F16 = false>

@@ -15,6 +15,8 @@
 //  * no barrier after the prologue: every wave runs at its own pace.
 // Accuracy scheme as in conv_gemm.hip (six cross products, MFMA partial sums folded into a master
 // accumulator with a round-to-nearest add every 64 input channels).
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace ddpm {
@@ -52,7 +54,9 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, u32x4& hi
 }
 
 // One wave's share: row groups g_begin + wr, + 4, ... of the workgroup's run, column blocks nb0 .. nb0 + NBW - 1.
-template <int NBW, bool F16>
+// WATCH: this wave watches the range of the activations it loads (F16); the two column halves load the same rows, so
+// the first half does the checking for both.
+template <int NBW, bool F16, bool WATCH>
 __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned char* wsm, int wr, int nb0, int lane);
 
 // With F16 the operands are fp16 pairs (conv_common.h): planes 0 and 1 of the packed weights, three MFMAs per step and
@@ -80,17 +84,17 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_resident_kernel(const Gem
     }
     __syncthreads();
     // the two column halves hold different numbers of blocks: each gets its own straight-line code
-    if (wn == 0) wave_body<NB0, F16>(p, wsm, wr, 0, lane);
-    else if (NB1 > 0) wave_body<(NB1 > 0 ? NB1 : 1), F16>(p, wsm, wr, NB0, lane);
+    if (wn == 0) wave_body<NB0, F16, true>(p, wsm, wr, 0, lane);
+    else if (NB1 > 0) wave_body<(NB1 > 0 ? NB1 : 1), F16, false>(p, wsm, wr, NB0, lane);
 }
 
-template <int NBW, bool F16>
+template <int NBW, bool F16, bool WATCH>
 __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned char* wsm, int wr, int nb0, int lane) {
     const int r = lane & 31, h = lane >> 5;
     const int g_begin = __builtin_amdgcn_readfirstlane(blockIdx.x * p.gpb);
     const int g_end = __builtin_amdgcn_readfirstlane(min(p.groups_total, g_begin + p.gpb));
     if (g_begin + wr >= g_end) return;
-    RangeWatch amax;   // F16: largest magnitude this thread has turned into an fp16 pair
+    std::conditional_t<WATCH, RangeWatch, NoWatch> amax;   // F16: largest magnitude this thread has turned into an fp16 pair
 
     const int kc16 = p.kc16;
     const int ntile = (g_end - g_begin - wr + 3) >> 2;        // row groups g_begin + wr, + 4, ...
@@ -263,7 +267,7 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
     if (s < nsteps) step(ra[0], bw0[0], bw0[1]);
     if (s + 1 < nsteps) step(ra[1], bw0[1], bw0[0]);
     if (s + 2 < nsteps) step(ra[2], bw0[0], bw0[1]);
-    if constexpr (F16) raise_range_flag(p.range_flag, amax);
+    if constexpr (F16 && WATCH) raise_range_flag(p.range_flag, amax);
 }
 
 template <int NB0, int NB1, bool F16>
@@ -293,7 +297,7 @@ int launch_one(const GemmParams& p, int grid, int lds, hipStream_t s) {
 // resident kernel and the generic one: the three agree bit for bit.
 constexpr int kSlabChunks = 4;
 
-template <int NBW, bool F16>
+template <int NBW, bool F16, bool WATCH>   // WATCH: as in wave_body; here only the first column tile's first half checks
 __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned char* wsm, int wr, int nb_in_tile, int nb_first, int nbt,
                                                int g_begin, int g_end, int lane, const __amdgpu_buffer_rsrc_t rs_w, unsigned tile_off) {
     const int tid = threadIdx.x;
@@ -372,7 +376,7 @@ __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned cha
         zero(acc[j]);
         zero(master[j]);
     }
-    RangeWatch amax;   // F16: largest magnitude this thread has turned into an fp16 pair
+    std::conditional_t<WATCH, RangeWatch, NoWatch> amax;   // F16: largest magnitude this thread has turned into an fp16 pair
 
     // step c (0..3) of the current slab
     auto step = [&](int c, f32x4 (&raw)[2], u32x4 (&b0cur)[NBW], u32x4 (&b0next)[NBW]) {
@@ -490,7 +494,7 @@ __device__ __forceinline__ void slab_wave_body(const GemmParams& p, unsigned cha
             ++t;
         }
     }
-    if constexpr (F16) raise_range_flag(p.range_flag, amax);
+    if constexpr (F16 && WATCH) raise_range_flag(p.range_flag, amax);
 }
 
 template <int NB0, int NB1, bool F16>
@@ -515,8 +519,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_slab_kernel(const GemmPar
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
     const unsigned tile_off = static_cast<unsigned>(ct * NBT) * 3072u;
     if (g_begin >= g_end) return;       // (whole workgroup: no barrier is skipped by part of it)
-    if (wn == 0) slab_wave_body<NB0, F16>(p, wsm, wr, 0, ct * NBT, NBT, g_begin, g_end, lane, rs_w, tile_off);
-    else slab_wave_body<(NB1 > 0 ? NB1 : 1), F16>(p, wsm, wr, NB0, ct * NBT + NB0, NBT, g_begin, g_end, lane, rs_w, tile_off);
+    if (wn == 0 && ct == 0) slab_wave_body<NB0, F16, true>(p, wsm, wr, 0, ct * NBT, NBT, g_begin, g_end, lane, rs_w, tile_off);
+    else if (wn == 0) slab_wave_body<NB0, F16, false>(p, wsm, wr, 0, ct * NBT, NBT, g_begin, g_end, lane, rs_w, tile_off);
+    else slab_wave_body<(NB1 > 0 ? NB1 : 1), F16, false>(p, wsm, wr, NB0, ct * NBT + NB0, NBT, g_begin, g_end, lane, rs_w, tile_off);
 }
 
 template <int NB0, int NB1, bool F16>

@@ -51,12 +51,12 @@ constexpr int kMaxLds = 160 * 1024 - 4096;
 constexpr int WM = 2, WN = 2;              // wave grid
 constexpr int BN = WN * 32;
 
-template <bool DUAL, bool F16, bool STATS>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
-    __shared__ __attribute__((aligned(16))) int rowb[256];   // sample index of every tile row, -1 = no such pixel
+// WATCH: this workgroup watches the range of the activations it stages (F16). The column tiles of one run of rows stage
+// the same activations, so the first of them does the checking for all.
+template <bool DUAL, bool F16, bool STATS, bool WATCH>
+__device__ __forceinline__ void conv3x3_halo_body(const GemmParams& p, int id, unsigned char* hsm, int* rowb) {
     if constexpr (F16) fp16_saturate();
-    RangeWatch amax;                           // F16: largest magnitude this thread has turned into an fp16 pair
+    std::conditional_t<WATCH, RangeWatch, NoWatch> amax;   // F16: largest magnitude this thread has turned into an fp16 pair
     constexpr int XR = F16 ? XROW_F16 : XROW;   // LDS bytes per tile row
     constexpr int NPL = F16 ? 2 : 3;            // operand planes
 
@@ -65,11 +65,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
     const int ZOFF = (2 * HBUF + 255) & ~255;   // 384 bytes of zeros behind the two buffers, 256-byte aligned
 
     const int nwg = gridDim.x;
-    int id = blockIdx.x;
-    {
-        const int q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
-        id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
-    }
     const int n_tile = id % p.n_tiles;
     const int m_block = id / p.n_tiles;
     const int n0 = n_tile * BN;
@@ -383,7 +378,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
             }
         }
     }
-    if constexpr (F16) raise_range_flag(p.range_flag, amax);
+    if constexpr (F16 && WATCH) raise_range_flag(p.range_flag, amax);
     if constexpr (STATS) {
         // the two lane halves hold different rows of the same column; so do the two waves with the same wn
         stat_sum += __shfl_xor(stat_sum, 32);
@@ -402,6 +397,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmPar
             dst[p.n_total] = stat_sq + red[(wn * 32 + r) * 2 + 1];
         }
     }
+}
+
+template <bool DUAL, bool F16, bool STATS>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_halo_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    __shared__ __attribute__((aligned(16))) int rowb[256];   // sample index of every tile row, -1 = no such pixel
+    int id = blockIdx.x;
+    {   // workgroups that share rows (the column tiles of one run) take consecutive numbers on ONE XCD
+        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = id & 7;
+        id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+    }
+    if (F16 && id % p.n_tiles == 0) conv3x3_halo_body<DUAL, F16, STATS, true>(p, id, hsm, rowb);
+    else conv3x3_halo_body<DUAL, F16, STATS, false>(p, id, hsm, rowb);
 }
 
 template <bool DUAL, bool F16, bool STATS = false>

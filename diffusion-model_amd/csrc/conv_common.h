@@ -173,6 +173,11 @@ static __device__ __forceinline__ void watch2(RangeWatch& w, const f32x2 v) {
     w.amax = __builtin_fmaxf(w.amax, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])));
     w.nan |= __builtin_isunordered(v[0], v[1]);
 }
+// A workgroup that stages an operand which another workgroup of the same launch stages too (and watches) passes this
+// instead: the splitting helpers are templates on the watch's type, and with this one they check nothing.
+struct NoWatch {};
+static __device__ __forceinline__ void watch2(NoWatch&, const f32x2) {}
+static __device__ __forceinline__ RangeWatch merged(const RangeWatch& a, const NoWatch&) { return a; }
 static __device__ __forceinline__ RangeWatch merged(const RangeWatch& a, const RangeWatch& b) {
     RangeWatch w;
     w.amax = __builtin_fmaxf(a.amax, b.amax);
@@ -184,7 +189,8 @@ static __device__ __forceinline__ void raise_range_flag(unsigned* flag, const Ra
 }
 
 // four consecutive channels of one tile row -> the two fp16 planes of that row (8 bytes each, 32 bytes apart)
-static __device__ __forceinline__ void split_store_f16(const f32x4 v, unsigned char* dst, RangeWatch& amax) {
+template <class W>
+static __device__ __forceinline__ void split_store_f16(const f32x4 v, unsigned char* dst, W& amax) {
     unsigned h0, l0, h1, l1;
     watch2(amax, f32x2{v[0], v[1]});
     watch2(amax, f32x2{v[2], v[3]});
@@ -195,7 +201,8 @@ static __device__ __forceinline__ void split_store_f16(const f32x4 v, unsigned c
 }
 
 // 8 consecutive fp32 (two 16-byte loads) -> the two fp16 planes of an MFMA operand fragment
-static __device__ __forceinline__ void split8_f16(const f32x4 v0, const f32x4 v1, u32x4& hi, u32x4& lo, RangeWatch& amax) {
+template <class W>
+static __device__ __forceinline__ void split8_f16(const f32x4 v0, const f32x4 v1, u32x4& hi, u32x4& lo, W& amax) {
     unsigned h[4], l[4];
     watch2(amax, f32x2{v0[0], v0[1]});
     watch2(amax, f32x2{v0[2], v0[3]});

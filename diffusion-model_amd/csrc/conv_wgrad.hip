@@ -255,7 +255,8 @@ __device__ __forceinline__ void split4_store(const f32x4 v, unsigned char* dst) 
     *reinterpret_cast<u32x2*>(dst + 2 * XPLANE) = lo;
 }
 
-__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, ddpm::conv::RangeWatch& amax) {
+template <class W>
+__device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* dst, W& amax) {
     unsigned h0, l0, h1, l1;
     ddpm::conv::watch2(amax, f32x2{v[0], v[1]});
     ddpm::conv::watch2(amax, f32x2{v[2], v[3]});
@@ -274,24 +275,23 @@ __device__ __forceinline__ void split4_store_f16(const f32x4 v, unsigned char* d
 // F16: both operands as fp16 pairs instead (hi, and the remainder scaled by 2^11; conv_common.h): two planes, three
 // MFMAs per fragment pair -- hi*hi into `acc`, the two cross products into `master`, which is scaled by 2^-11 and
 // added at the end -- and no fold (the fp16 MFMA accumulates without drift).
-template <int MODE, int PAIR, bool F16>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams p) {
+//
+// WATCH (F16): this workgroup watches the range of the operands it stages. The same pixels of dY and X are staged by
+// every tap group and by every channel tile of the other operand, so the kernel below picks the workgroups whose
+// loads together cover both tensors once and gives only those the checking code.
+template <int MODE, int PAIR, bool F16, bool WATCH>
+__device__ __forceinline__ void conv_wgrad_x3_body(const WgradParams& p, int id, unsigned char* sA_mem, unsigned char* sB_mem) {
     static_assert(PAIR == 0 || MODE == WG_CONV3, "two taps per tile exist for the 3x3 convolution only");
     if constexpr (F16) ddpm::conv::fp16_saturate();
-    ddpm::conv::RangeWatch amax;                     // F16: largest magnitude this thread has turned into an fp16 pair
+    std::conditional_t<WATCH, ddpm::conv::RangeWatch, ddpm::conv::NoWatch> amax;   // F16: largest magnitude this thread has turned into an fp16 pair
     constexpr int BT = 128;
     constexpr int NPL = F16 ? 2 : 3;      // operand planes
     constexpr int F4R = BT / 4;           // float4 per tile row
     constexpr int LPT = XKP * F4R / 256;  // float4 loads per thread per operand (2)
     constexpr int RSTEP = 256 / F4R;      // rows between a thread's consecutive loads (8)
-    __shared__ __attribute__((aligned(16))) unsigned char sA[2][NPL * XPLANE];
-    __shared__ __attribute__((aligned(16))) unsigned char sB[2][NPL * XPLANE];
+    unsigned char (*sA)[NPL * XPLANE] = reinterpret_cast<unsigned char (*)[NPL * XPLANE]>(sA_mem);   // [2]
+    unsigned char (*sB)[NPL * XPLANE] = reinterpret_cast<unsigned char (*)[NPL * XPLANE]>(sB_mem);   // [2]
 
-    // Workgroups are handed to the 8 XCDs round-robin and each XCD has its own L2: renumber so that an
-    // XCD runs CONSECUTIVE work items, i.e. the taps and channel tiles that read the same pixels share
-    // one L2 instead of each fetching its own copy over the fabric.
-    int id = static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
-    if (id >= p.work) return;
     const int nt = id % p.n_tiles; id /= p.n_tiles;
     const int mt = id % p.m_tiles; id /= p.m_tiles;
     const int tg = id % p.tap_groups;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
             for (int j = 0; j < 2; ++j) master[i][j] = acc[i][j] + master[i][j] * kLoInv;
     }
 
-    if constexpr (F16) ddpm::conv::raise_range_flag(p.range_flag, amax);
+    if constexpr (F16 && WATCH) ddpm::conv::raise_range_flag(p.range_flag, amax);
     if (wave_tap >= p.taps) return;
     float* outp = p.out + static_cast<int64_t>(wave_tap) * p.m_total * p.n_total;
 #pragma unroll
@@ -613,6 +613,40 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
                 if (m < p.m_total && (!(DDPM_WG_ABLATE & 32) || master[i][j][e] == 1.2345f)) atomicAdd(outp + static_cast<int64_t>(m) * p.n_total + n, master[i][j][e]);
             }
     }
+}
+
+template <int MODE, int PAIR, bool F16>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams p) {
+    constexpr int NPL = F16 ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) unsigned char sA[2 * NPL * XPLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char sB[2 * NPL * XPLANE];
+    // Workgroups are handed to the 8 XCDs round-robin and each XCD has its own L2: renumber so that an
+    // XCD runs CONSECUTIVE work items, i.e. the taps and channel tiles that read the same pixels share
+    // one L2 instead of each fetching its own copy over the fabric.
+    const int id = static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    if (id >= p.work) return;
+    bool watch = false;
+    if constexpr (F16) {
+        // A (dY) is loaded unshifted and B (X) shifted by the tap, except with PAIR = 2 (the other way round) and for the
+        // transposed convolution (every tap gathers its own quarter of dY, X is unshifted). The unshifted operand is
+        // checked by the first tap group, the shifted one by the centre tap (whose window is the chunk itself) or, where
+        // taps share a tile, by all of them; each by the first channel tile of the other operand only.
+        const int nt = id % p.n_tiles, mt = (id / p.n_tiles) % p.m_tiles, tg = (id / (p.n_tiles * p.m_tiles)) % p.tap_groups;
+        bool wa, wb;
+        if (MODE == WG_CONVT || PAIR == 2) {
+            wa = nt == 0;
+            wb = tg == 0 && mt == 0;
+        } else if (PAIR == 1) {
+            wa = tg == 0 && nt == 0;
+            wb = mt == 0;
+        } else {
+            wa = tg == 0 && nt == 0;
+            wb = tg == p.taps / 2 && mt == 0;
+        }
+        watch = wa || wb;
+    }
+    if (watch) conv_wgrad_x3_body<MODE, PAIR, F16, F16>(p, id, sA, sB);
+    else conv_wgrad_x3_body<MODE, PAIR, F16, false>(p, id, sA, sB);
 }
 
 // The split-K partial sums meet in `out` through atomic adds, so it starts at zero. A plain kernel of
