@@ -295,3 +295,122 @@ def test_training_moves_to_full_range_arithmetic_after_a_step_that_left_the_rang
         worst.append((err / (2e-3 * ref.abs().max().item() + 5e-6), k))
     worst.sort(reverse=True)
     assert worst[0][0] <= 1.0, worst[:5]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Where several workgroups of a launch stage the same operand, only one of them checks it (the first column tile,
+# query block, key block or tap group). These tests put ONE out-of-range element at many places of every operand --
+# first and last rows, samples, channels, chunk boundaries -- and require the flag each time: no element may fall
+# between the workgroups that do the checking.
+def _positions(shape, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    corners = [tuple(0 for _ in shape), tuple(s - 1 for s in shape)]
+    rand = [tuple(int(torch.randint(0, s, (1,), generator=g)) for s in shape) for _ in range(n)]
+    return corners + rand
+
+
+@pair_default
+@pytest.mark.parametrize("ci,co,hw,batch", [(128, 128, 16, 40), (64, 256, 8, 70), (256, 64, 12, 33), (64, 64, 28, 24)])
+def test_conv3x3_and_its_weight_gradient_flag_a_bad_element_anywhere(ci, co, hw, batch):
+    x = torch.randn((batch, hw, hw, ci), device="cuda")
+    dy = torch.randn((batch, hw, hw, co), device="cuda")
+    w = torch.randn((co, ci, 3, 3), device="cuda") * 0.05
+    wp = torch.empty(packed_floats(9, co, ci), device="cuda")
+    call("ddpm_pack_conv3x3", P(w), co, ci, 0, P(wp), stream())
+    out = torch.empty((batch, hw, hw, co), device="cuda")
+    d = ConvDesc(batch=batch, in_h=hw, in_w=hw, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=0, ldr=0, out_h=hw, out_w=hw)
+    ep = Epilogue(None, None, None, None)
+    packed, gw = torch.empty(co * ci * 9, device="cuda"), torch.empty((co, ci, 3, 3), device="cuda")
+
+    def fwd():
+        call("ddpm_conv3x3_fwd", C.byref(d), P(x), None, P(wp), C.byref(ep), P(out), stream())
+
+    def wgrad():
+        call("ddpm_conv3x3_wgrad", P(dy), co, co, P(x), ci, ci, batch, hw, hw, P(packed), P(gw), stream())
+
+    read_flag()
+    fwd()
+    wgrad()
+    assert read_flag() == 0
+    for pos in _positions(x.shape, 6, 1):
+        keep = x[pos].item()
+        x[pos] = 1.0e5
+        for what, run in (("forward", fwd), ("weight gradient, X", wgrad)):
+            run()
+            assert read_flag() == 1, (what, pos)
+        x[pos] = keep
+    for pos in _positions(dy.shape, 6, 2):
+        keep = dy[pos].item()
+        dy[pos] = -3.0e5
+        wgrad()
+        assert read_flag() == 1, ("weight gradient, dY", pos)
+        dy[pos] = keep
+    fwd()
+    wgrad()
+    assert read_flag() == 0
+
+
+@pair_default
+@pytest.mark.parametrize("rows,ci,co", [(20000, 128, 160), (17000, 256, 320), (16500, 512, 640), (3000, 128, 160)])
+def test_conv1x1_flags_a_bad_element_anywhere(rows, ci, co):
+    x = torch.randn((rows, ci), device="cuda")
+    w = torch.randn((co, ci), device="cuda") * ci ** -0.5
+    wp = torch.empty(packed_floats(1, co, ci), device="cuda")
+    call("ddpm_pack_conv1x1", P(w), co, ci, 0, P(wp), stream())
+    d = ConvDesc(batch=1, in_h=rows, in_w=1, c1=ci, ld1=ci, c2=0, ld2=0, cout=co, ldo=co, act=0, ldr=0, out_h=rows, out_w=1)
+    ep = Epilogue(None, None, None, None)
+    out = torch.empty((rows, co), device="cuda")
+    read_flag()
+    for pos in _positions(x.shape, 8, 3):
+        keep = x[pos].item()
+        x[pos] = 7.0e4
+        call("ddpm_conv1x1_fwd", C.byref(d), P(x), None, P(wp), C.byref(ep), P(out), stream())
+        assert read_flag() == 1, pos
+        x[pos] = keep
+    call("ddpm_conv1x1_fwd", C.byref(d), P(x), None, P(wp), C.byref(ep), P(out), stream())
+    assert read_flag() == 0
+
+
+@pair_default
+@pytest.mark.parametrize("b,n,c,dq", [(3, 784, 128, 16), (2, 1024, 64, 8), (5, 200, 128, 16)])
+def test_attention_forward_and_backward_flag_a_bad_element_anywhere(b, n, c, dq):
+    qkv = torch.randn((b, n, 2 * dq + c), device="cuda") * 0.3
+    xin, dy = torch.randn((b, n, c), device="cuda"), torch.randn((b, n, c), device="cuda")
+    gamma = torch.tensor([0.7], device="cuda")
+    out, raw, lse = torch.empty((b, n, c), device="cuda"), torch.empty((b, n, c), device="cuda"), torch.empty((b, n), device="cuda")
+    dqkv, dgamma = torch.empty_like(qkv), torch.empty(1, device="cuda")
+    ws, es = torch.empty(4096, dtype=torch.float64, device="cuda"), torch.empty((b, n), device="cuda")
+
+    def fwd(train):
+        call("ddpm_attention_fwd", P(qkv), P(xin), c, P(gamma), P(out), c, P(raw) if train else None, P(lse) if train else None, None,
+             b, n, c, dq, stream())
+
+    def bwd():
+        call("ddpm_attention_bwd", P(qkv), P(dy), c, P(raw), P(lse), P(gamma), P(ws), P(es), P(dqkv), P(dgamma), b, n, c, dq, stream())
+
+    read_flag()
+    fwd(True)
+    bwd()
+    fwd(False)
+    assert read_flag() == 0
+    for pos in _positions(qkv.shape, 8, 4):
+        keep = qkv[pos].item()
+        fwd(True)                      # a clean forward: the backward below sees the bad element in qkv only
+        read_flag()
+        qkv[pos] = 9.0e4
+        bwd()
+        assert read_flag() == 1, ("backward, q|k|v", pos)
+        for train in (False, True):
+            fwd(train)
+            assert read_flag() == 1, ("forward", train, pos)
+        qkv[pos] = keep
+    fwd(True)
+    read_flag()
+    for pos in _positions(dy.shape, 8, 5):
+        keep = dy[pos].item()
+        dy[pos] = -2.0e5
+        bwd()
+        assert read_flag() == 1, ("backward, dY", pos)
+        dy[pos] = keep
+    bwd()
+    assert read_flag() == 0
