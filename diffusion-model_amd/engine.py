@@ -90,6 +90,8 @@ class UNetEngine(TrainMixin):
         self.math = None
         self.range_fallbacks = 0       # how often this network has left the fp16 pair because of such an operand
         self._range_pending = None     # (event, slot): a flag read-back enqueued and not yet examined
+        self._range_unread = False     # watched kernels of this network were enqueued after its last read-back
+        self._range_external = False   # a caller (sample()) reads the flag itself: run() neither clears nor posts
         self._range_host = None        # pinned int32 words the read-backs land in
         self._labels_pending = []      # deferred label range checks of training steps: (event, pinned verdict, classes)
         self.prof = None       # when a list: (kernel label, flops, start event, end event) per sampled MFMA launch
@@ -171,12 +173,13 @@ class UNetEngine(TrainMixin):
         """Enqueue a read-and-clear of the flag without waiting; range_poll examines it once the GPU has got there.
         (While one is pending no second one is enqueued: the flag stays raised on the device until it is read.)"""
         if self._range_pending is not None:
-            return
+            return                     # (_range_unread stays set: a later post picks the flag up)
         host = self._range_slot()
         call("ddpm_range_flag_read", C.c_void_p(host.data_ptr() + 4), 1, _stream())
         ev = torch.cuda.Event()
         ev.record()
         self._range_pending = ev
+        self._range_unread = False
 
     def range_poll(self):
         """Examine a pending read-back if the GPU has finished it (never waits). An operand beyond fp16's range
@@ -211,13 +214,15 @@ class UNetEngine(TrainMixin):
     def run(self, x, t, y, training):
         if self._labels_pending and not torch.cuda.is_current_stream_capturing():
             self._poll_labels()
-        if self.range_watching():
+        own_watch = self.range_watching() and not self._range_external
+        if own_watch:
             self.range_poll()
-            if self._range_pending is None:
+            if self._range_pending is None and not self._range_unread:
                 self.range_clear()     # the flag is one word per GPU: whatever other work raised it is not this call's
+            self._range_unread = True  # watched kernels of this network follow; the next read-back covers them
         with self.math_scope():
             out = self._run(x, t, y, training)
-        if self.range_watching() and not (torch.is_grad_enabled() and training):
+        if own_watch and self.range_watching() and not (torch.is_grad_enabled() and training):
             self.range_post()      # (a differentiated training forward posts after its backward)
         return out
 

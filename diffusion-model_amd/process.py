@@ -108,10 +108,27 @@ class _DiffusionBase:
         ckpt = None
         if watch:
             eng.range_poll()
+            if eng._range_unread or eng._range_pending is not None:
+                # an earlier call of this network has not had its flag read yet: settle that first
+                hit = eng.range_check_sync()
+                eng.range_poll()
+                eng._range_unread = False
+                if hit and eng.range_watching():
+                    eng.range_fallback("an earlier call")
             watch = eng.range_watching()
         if watch:
             eng.range_clear()
             ckpt = self._checkpoint(x_t, T - 1, zi, len(stages))
+        external_before = eng._range_external if eng is not None else False
+        if eng is not None:
+            eng._range_external = True       # model calls inside the loop leave the flag to the checks below
+        try:
+            return self._sample_loop(x_shape, x_t, T, zs, zi, stages, labels, cfg_scale, philox, seed, fused, eng, watch, ckpt)
+        finally:
+            if eng is not None:
+                eng._range_external = external_before
+
+    def _sample_loop(self, x_shape, x_t, T, zs, zi, stages, labels, cfg_scale, philox, seed, fused, eng, watch, ckpt):
         t = T
         while t > 0:
             t -= 1

@@ -414,3 +414,34 @@ def test_attention_forward_and_backward_flag_a_bad_element_anywhere(b, n, c, dq)
         dy[pos] = keep
     bwd()
     assert read_flag() == 0
+
+
+@pair_default
+@pytest.mark.parametrize("fuse", [True, False])
+def test_guided_sampling_falls_back_as_a_whole_segment(fuse):
+    """Classifier-free guidance calls the network twice per step (third-iteration/diffusion.py:34-41), once through the
+    plain forward: that call must leave the flag to sample(), which repeats the whole segment -- the result equals a run
+    on three bf16 planes from the start, bit for bit, with and without the fused last kernel."""
+    T, shape = 10, (2, 1, 28, 28)
+    xT = seeded_tensor(shape, 5, "xT") * 3.0e5
+    zs = [seeded_tensor(shape, 5, f"z{i}") for i in range(T - 1)]
+    labels = torch.tensor([3])
+    outs = []
+    for start_full in (False, True):
+        m = pkg.make_unet_class(3)(1, 1, 8, 16, num_classes=10)
+        m.load_state_dict(seeded_state_dict(m.state_dict(), 4))
+        m = m.cuda().eval()
+        if start_full:
+            m._engine.math = "bf16x3"
+        cls = pkg.make_diffusion_class(3)
+        dm = cls(m, pkg.BetaScheduler(T, device="cuda").get_schedule("linear"), T)
+        dm.fuse_final_step = fuse
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            with torch.no_grad():
+                outs.append(dm.sample(shape, "cuda", labels=labels, cfg_scale=2.0, noise=(xT, zs)))
+        assert len([w for w in rec if issubclass(w.category, RuntimeWarning)]) == (0 if start_full else 1)
+        assert m._engine.math == "bf16x3" and m._engine.range_fallbacks == (0 if start_full else 1)
+        assert not m._engine._range_external
+    assert all(torch.equal(a[0], b[0]) and a[1] == b[1] for a, b in zip(*outs))
+    assert max(s[0].abs().max().item() for s in outs[0]) > 1e5
