@@ -277,9 +277,9 @@ class Job:
                     tt = torch.full((B,), t, dtype=torch.long, device=dev)
                     c1, c2, c3 = step_coefficients_host(dm._betas_h[t], dm._alphas_h[t], dm._abar_h[t])
                     if args.noise == "philox":          # drawn inside the fused last kernel
-                        step = dict(c1=c1, c2=c2, c3=c3, noise_mode=2, z=None, seed=1234 + rank, call=t, t_uniform=True)
+                        step = dict(c1=c1, c2=c2, c3=c3, noise_mode=2, z=None, seed=1234 + rank, call=t, t_uniform=True, want_fms=False)
                     else:                               # what sample() does by default: torch's device generator
-                        step = dict(c1=c1, c2=c2, c3=c3, noise_mode=1, z=torch.randn_like(x), t_uniform=True)
+                        step = dict(c1=c1, c2=c2, c3=c3, noise_mode=1, z=torch.randn_like(x), t_uniform=True, want_fms=False)
                     out = model.denoise_step(x, tt, labels, step)     # UNet forward whose last layer is fused with the update
                 if t > 1:
                     state["x"], state["t"] = out, t - 1

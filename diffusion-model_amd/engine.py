@@ -259,7 +259,7 @@ class UNetEngine(TrainMixin):
                 raise AttributeError("this UNet was built without num_classes; it has no label embedding")
             y = y.to(device=x.device, dtype=torch.int64).contiguous()
         with torch.no_grad(), self.math_scope():
-            return self.forward_eval(x, t, y, step=step)
+            return self.forward_eval(x, t, y, want_fms=bool(step.get("want_fms", True)), step=step)
 
     # ------------------------------------------------------------------ parameters and caches
     def T(self, key):
@@ -577,6 +577,12 @@ class UNetEngine(TrainMixin):
 
         def tail(src, key_conv, key_attn, cout, te, h, w):
             """DoubleConv (+attention) + embedding add; returns the tensor handed to the next block."""
+            if v1 and not want_fms:
+                # nobody looks at the feature map (a sampling step): the embedding is added in the conv's epilogue,
+                # the same fp32 addition on the same values as the separate kernel below
+                post = View(buf(h, w, cout))
+                self.double_conv_eval(src, key_conv, cout, post, temb=te)
+                return post
             if v1:
                 pre = View(buf(h, w, cout))
                 self.double_conv_eval(src, key_conv, cout, pre)

@@ -143,8 +143,10 @@ class _DiffusionBase:
                     z = torch.randn_like(x_t)                # per-step noise from the device generator
             if fused:
                 # the UNet's final 1x1 conv and the update are one kernel: eps-hat is consumed where it is produced
+                # (t_tensor is torch.full: one embedding row serves the whole batch; model.feature_maps holds the LAST
+                # step's maps after the call, as after the reference's loop: the steps before it need not produce them)
                 step = dict(c1=c1, c2=c2, c3=c3, noise_mode=0 if t == 0 else (2 if philox else 1), z=z, seed=seed, call=t,
-                            t_uniform=True)      # t_tensor is torch.full: one embedding row serves the whole batch
+                            t_uniform=True, want_fms=(t == 0))
                 x_t = x_t.contiguous()
                 if cfg_scale > 0:
                     step.update(eps_cond=self._model_call(x_t, t_tensor, labels).contiguous(), cfg_w=float(cfg_scale))

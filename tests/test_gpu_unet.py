@@ -105,6 +105,8 @@ def test_sample_draws_its_own_noise_and_too_few_steps():
         stages = dm.sample((2, 1, 16, 16), "cuda")
     assert [s[1] for s in stages] == list(range(9, -1, -1))
     assert all(torch.isfinite(s[0]).all() for s in stages)
+    # model.feature_maps holds the maps of the loop's last forward, as after the reference's loop (first-iteration/unet.py:76-112)
+    assert len(m.feature_maps) == 7 and all(torch.isfinite(f).all() for f in m.feature_maps)
     dm5 = pkg.make_diffusion_class(1)(m, pkg.BetaScheduler(5, device="cuda").get_schedule("linear"), 5)
     with pytest.raises(ZeroDivisionError):          # the reference divides by T // 10
         with torch.no_grad():
