@@ -86,6 +86,7 @@ _SIGNATURES = {
     "ddpm_time_embed_bwd": [C.POINTER(EmbedBwdArgs), P],
     "ddpm_attention_bwd": [P, P, I32, P, P, P, P, P, P, P, I32, I32, I32, I32, P],
     "ddpm_attention_fwd": [P, P, I32, P, P, I32, P, P, P, I32, I32, I32, I32, P],
+    "ddpm_self_attention_infer": [P, I32, P, P, P, P, P, I32, P, I32, I32, I32, I32, P],
     "ddpm_softmax_rows": [P, I64, I32, P, P],
     "ddpm_inception_split_scores": [P, I64, I32, I32, P, P],
     "ddpm_mean_cov": [P, I64, I32, P, P, P, P],

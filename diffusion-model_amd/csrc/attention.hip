@@ -42,7 +42,20 @@ struct AttnParams {
     float* lse;         // optional [B][N]
     int n, c, dqp, lq, ldx, ldo;
     unsigned* range_flag;   // fp16-pair kernels: raised when q, k or v lies beyond fp16's range
+    // PRE kernels (inference, fp16 pair): the projection has split k and v already. qkv then holds q | k only (lq = 2 dqp),
+    // every k element as one (hi | lo << 16) word; v is here, as pair planes in operand order: 16 bytes (the eight keys
+    // 16ck + 4h + i and 16ck + 8 + 4h + i, i < 4, that half h of a matrix operand takes from 16-key chunk ck) at
+    // [row / 16 = chunk][h][plane][channel], rows counted over the whole batch (n is a multiple of 32).
+    const unsigned char* vpl;
 };
+
+// four k elements as (hi | lo << 16) words -> their two plane words each, into a K row of the tile
+__device__ __forceinline__ void unzip4_store(const f32x4 v, unsigned char* dst, int plane_stride) {
+    const unsigned w0 = __float_as_uint(v[0]), w1 = __float_as_uint(v[1]), w2 = __float_as_uint(v[2]), w3 = __float_as_uint(v[3]);
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u)};
+    *reinterpret_cast<u32x2_t*>(dst + plane_stride) = u32x2_t{__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u)};
+}
 
 template <int DQ, int NCT>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnParams p) {
@@ -303,8 +316,10 @@ using ddpm::conv::mfma16;
 // KVW: this workgroup watches the range of the K and V tiles it stages (the first query block of a sample does it for
 // all of them: they stage the same tiles); each watches its own queries. The tile buffers are the caller's, so that
 // the two instantiations inside one kernel share them.
-template <int DQ, int QB, int NCT, bool F16, bool KVW>
+// PRE: k and v arrive split (AttnParams::vpl): the staging is a copy and the V fragments are plain 16-byte reads.
+template <int DQ, int QB, int NCT, bool F16, bool KVW, bool PRE = false>
 __device__ __forceinline__ void attention_fwd_x3_body(const AttnParams& p, const dim3 bid, unsigned char* sK_mem, unsigned char* sV_mem) {
+    static_assert(!PRE || (F16 && !KVW), "pre-split operands are fp16 pairs, checked where they were split");
     if constexpr (F16) ddpm::conv::fp16_saturate();
     ddpm::conv::RangeWatch amax;                           // F16: largest magnitude of q this thread has turned into an fp16 pair
     ddpm::conv::NoWatch unwatched_kv;
@@ -321,12 +336,12 @@ __device__ __forceinline__ void attention_fwd_x3_body(const AttnParams& p, const
     constexpr int VROW = CS * 2 + 64;           // V row of one plane + pad (transposed reads conflict-free)
     constexpr int VPLANE = KT * VROW;
     constexpr int KF4 = KT * DQ / 4;            // float4 per K tile
-    constexpr int VF4 = KT * CS / 4;            // float4 per V tile
+    constexpr int VF4 = KT * CS / 4;            // float4 per V tile (PRE: 16-byte pieces [chunk][h][plane][channel], as many)
     constexpr int KPT = (KF4 + 255) / 256, VPT = VF4 / 256;
     static_assert(VF4 % 256 == 0, "V tile must split evenly over 256 threads");
 
     unsigned char (*sK)[KT * KROW] = reinterpret_cast<unsigned char (*)[KT * KROW]>(sK_mem);        // [2]
-    unsigned char (*sV)[NPL * VPLANE] = reinterpret_cast<unsigned char (*)[NPL * VPLANE]>(sV_mem);  // [2]
+    unsigned char (*sV)[NPL * VPLANE] = reinterpret_cast<unsigned char (*)[NPL * VPLANE]>(sV_mem);  // [2] (PRE uses 16 * VF4 bytes of each)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -388,6 +403,9 @@ __device__ __forceinline__ void attention_fwd_x3_body(const AttnParams& p, const
     // K and V rows come through a range-checked descriptor over the sample's [n][lq] block: rows past the last key
     // and channels past the last one read as zero without a branch
     const __amdgpu_buffer_rsrc_t rs_kv = ddpm::buffer_over(base, static_cast<long long>(p.n) * p.lq * 4ll);
+    // PRE: the sample's v planes (n * c * 4 bytes, tile t at t * 128 * c)
+    const __amdgpu_buffer_rsrc_t rs_v = ddpm::buffer_over(
+        PRE ? reinterpret_cast<const float*>(p.vpl + static_cast<int64_t>(b) * p.n * p.c * 4) : base, PRE ? static_cast<long long>(p.n) * p.c * 4ll : 0ll);
     auto load_tile = [&](int j0) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
@@ -398,8 +416,13 @@ __device__ __forceinline__ void attention_fwd_x3_body(const AttnParams& p, const
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int f = tid + 256 * i;
-            const int row = f / (CS / 4), c4 = f % (CS / 4);
-            vreg[i] = ddpm::buffer_load4(rs_kv, cbase + c4 * 4 < p.c ? static_cast<unsigned>((j0 + row) * p.lq + 2 * p.dqp + cbase + c4 * 4) * 4u : ddpm::kOob);
+            if constexpr (PRE) {
+                const int g = f / CS, ch = f % CS;   // g = (chunk of the tile, h, plane)
+                vreg[i] = ddpm::buffer_load4(rs_v, cbase + ch < p.c ? static_cast<unsigned>(((j0 >> 4) * 4 + g) * p.c + cbase + ch) * 16u : ddpm::kOob);
+            } else {
+                const int row = f / (CS / 4), c4 = f % (CS / 4);
+                vreg[i] = ddpm::buffer_load4(rs_kv, cbase + c4 * 4 < p.c ? static_cast<unsigned>((j0 + row) * p.lq + 2 * p.dqp + cbase + c4 * 4) * 4u : ddpm::kOob);
+            }
         }
     };
     auto store_tile = [&](int buf) {
@@ -408,7 +431,8 @@ __device__ __forceinline__ void attention_fwd_x3_body(const AttnParams& p, const
             const int f = tid + 256 * i;
             const int row = f / (DQ / 4), c4 = f % (DQ / 4);
             if (f < KF4) {
-                if constexpr (F16) split4_store_f16(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL, kvw);
+                if constexpr (PRE) unzip4_store(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL);
+                else if constexpr (F16) split4_store_f16(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL, kvw);
                 else split4_store(kreg[i], &sK[buf][row * KROW + c4 * 8], KPL);
             }
         }
@@ -416,7 +440,8 @@ __device__ __forceinline__ void attention_fwd_x3_body(const AttnParams& p, const
         for (int i = 0; i < VPT; ++i) {
             const int f = tid + 256 * i;
             const int row = f / (CS / 4), c4 = f % (CS / 4);
-            if constexpr (F16) split4_store_f16(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE, kvw);
+            if constexpr (PRE) *reinterpret_cast<f32x4*>(&sV[buf][f * 16]) = vreg[i];
+            else if constexpr (F16) split4_store_f16(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE, kvw);
             else split4_store(vreg[i], &sV[buf][row * VROW + c4 * 8], VPLANE);
         }
     };
@@ -539,6 +564,10 @@ __device__ __forceinline__ void attention_fwd_x3_body(const AttnParams& p, const
                                 vf[c2][pl] = qf[0][0][pl];
                                 continue;
                             }
+                            if constexpr (PRE) {
+                                vf[c2][pl] = *reinterpret_cast<const u32x4*>(&sV[buf][((((ck * 2 + h) * 2 + pl) * CS) + (ct0 + c2) * 32 + r) * 16]);
+                                continue;
+                            }
                             const unsigned char* src = &sV[buf][pl * VPLANE + (16 * ck) * VROW + (ct0 + c2) * 64 + vlane];
                             const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src));
                             const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src + 8 * VROW));
@@ -613,14 +642,15 @@ __device__ __forceinline__ void attention_fwd_x3_body(const AttnParams& p, const
     }
 }
 
-template <int DQ, int QB, int NCT, bool F16>
+template <int DQ, int QB, int NCT, bool F16, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnParams p) {
     constexpr int NPL = F16 ? 2 : 3, KD = DQ < 16 ? 16 : DQ;
     constexpr int KROW = NPL * KD * 2 + 16, VPLANE = KT * (32 * NCT * 2 + 64);   // as in the body
     __shared__ __attribute__((aligned(16))) unsigned char sK[2 * KT * KROW];
     __shared__ __attribute__((aligned(16))) unsigned char sV[2 * NPL * VPLANE];
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
-    if (F16 && bid.x == 0) attention_fwd_x3_body<DQ, QB, NCT, F16, true>(p, bid, sK, sV);
+    if constexpr (PRE) attention_fwd_x3_body<DQ, QB, NCT, F16, false, true>(p, bid, sK, sV);
+    else if (F16 && bid.x == 0) attention_fwd_x3_body<DQ, QB, NCT, F16, true>(p, bid, sK, sV);
     else attention_fwd_x3_body<DQ, QB, NCT, F16, false>(p, bid, sK, sV);
 }
 
@@ -635,8 +665,10 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_x3_kernel(const AttnPara
 // same order per query as the kernel above: the results are bit-identical.
 // KVW: this workgroup watches the range of the K and V tiles it stages. Every query block of a sample stages the same
 // K and V, so one of them (the first) does the checking for all; each checks its own queries.
-template <int DQ, int NCT, int NW, bool F16, bool KVW>
+// PRE: k and v arrive split (AttnParams::vpl): the staging is a copy and the V fragments are plain 16-byte reads.
+template <int DQ, int NCT, int NW, bool F16, bool KVW, bool PRE = false>
 __device__ __forceinline__ void attention_fwd_x3p_body(const AttnParams& p, const dim3 bid) {
+    static_assert(!PRE || (F16 && !KVW), "pre-split operands are fp16 pairs, checked where they were split");
     if constexpr (F16) ddpm::conv::fp16_saturate();
     ddpm::conv::RangeWatch amax;                   // F16: largest magnitude of q this thread has turned into an fp16 pair
     ddpm::conv::NoWatch unwatched_kv;
@@ -653,7 +685,7 @@ __device__ __forceinline__ void attention_fwd_x3p_body(const AttnParams& p, cons
     constexpr int KF4 = KT * DQ / 4, VF4 = KT * CS / 4;
     constexpr int KPT = (KF4 + NT - 1) / NT, VPT = VF4 / NT;
     static_assert(VF4 % NT == 0, "V tile must split evenly over the workgroup");
-    constexpr int KBUF = KT * KROW, VBUF = NPL * VPLANE;
+    constexpr int KBUF = KT * KROW, VBUF = PRE ? 16 * VF4 : NPL * VPLANE;   // PRE: 16-byte pieces [chunk][h][plane][channel]
     constexpr float kLog2e = 1.4426950408889634f;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
@@ -719,26 +751,36 @@ __device__ __forceinline__ void attention_fwd_x3p_body(const AttnParams& p, cons
             kreg[i] = ddpm::buffer_load4(rs_kv, f < KF4 ? static_cast<unsigned>((j0 + row) * p.lq + p.dqp + c4 * 4) * 4u : ddpm::kOob);
         }
     };
+    // PRE: the sample's v planes (n * c * 4 bytes, tile t at t * 128 * c)
+    const __amdgpu_buffer_rsrc_t rs_v = ddpm::buffer_over(
+        PRE ? reinterpret_cast<const float*>(p.vpl + static_cast<int64_t>(b) * p.n * p.c * 4) : base, PRE ? static_cast<long long>(p.n) * p.c * 4ll : 0ll);
     auto load_v = [&](int j0) {
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int f = tid + NT * i;
-            const int row = f / (CS / 4), c4 = f % (CS / 4);
-            vreg[i] = ddpm::buffer_load4(rs_kv, cbase + c4 * 4 < p.c ? static_cast<unsigned>((j0 + row) * p.lq + 2 * p.dqp + cbase + c4 * 4) * 4u : ddpm::kOob);
+            if constexpr (PRE) {
+                const int g = f / CS, ch = f % CS;   // g = (chunk of the tile, h, plane)
+                vreg[i] = ddpm::buffer_load4(rs_v, cbase + ch < p.c ? static_cast<unsigned>(((j0 >> 4) * 4 + g) * p.c + cbase + ch) * 16u : ddpm::kOob);
+            } else {
+                const int row = f / (CS / 4), c4 = f % (CS / 4);
+                vreg[i] = ddpm::buffer_load4(rs_kv, cbase + c4 * 4 < p.c ? static_cast<unsigned>((j0 + row) * p.lq + 2 * p.dqp + cbase + c4 * 4) * 4u : ddpm::kOob);
+            }
         }
     };
     auto store_k1 = [&](int i, unsigned char* dst) {
         const int f = tid + NT * i;
         const int row = f / (DQ / 4), c4 = f % (DQ / 4);
         if (f < KF4) {
-            if constexpr (F16) split4_store_f16(kreg[i], dst + row * KROW + c4 * 8, KPL, kvw);
+            if constexpr (PRE) unzip4_store(kreg[i], dst + row * KROW + c4 * 8, KPL);
+            else if constexpr (F16) split4_store_f16(kreg[i], dst + row * KROW + c4 * 8, KPL, kvw);
             else split4_store(kreg[i], dst + row * KROW + c4 * 8, KPL);
         }
     };
     auto store_v1 = [&](int i, unsigned char* dst) {
         const int f = tid + NT * i;
         const int row = f / (CS / 4), c4 = f % (CS / 4);
-        if constexpr (F16) split4_store_f16(vreg[i], dst + row * VROW + c4 * 8, VPLANE, kvw);
+        if constexpr (PRE) *reinterpret_cast<f32x4*>(dst + f * 16) = vreg[i];
+        else if constexpr (F16) split4_store_f16(vreg[i], dst + row * VROW + c4 * 8, VPLANE, kvw);
         else split4_store(vreg[i], dst + row * VROW + c4 * 8, VPLANE);
     };
 
@@ -822,6 +864,10 @@ __device__ __forceinline__ void attention_fwd_x3p_body(const AttnParams& p, cons
         const int ck = blk / NCT, ct = blk % NCT;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
+            if constexpr (PRE) {
+                vf[pl] = *reinterpret_cast<const u32x4*>(vb + ((((ck * 2 + h) * 2 + pl) * CS) + ct * 32 + r) * 16);
+                continue;
+            }
             const unsigned char* src = vb + pl * VPLANE + (16 * ck) * VROW + ct * 64 + vlane;
             const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src));
             const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src + 8 * VROW));
@@ -997,22 +1043,23 @@ __device__ __forceinline__ void attention_fwd_x3p_body(const AttnParams& p, cons
     }
 }
 
-template <int DQ, int NCT, int NW, bool F16>
+template <int DQ, int NCT, int NW, bool F16, bool PRE = false>
 __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_x3p_kernel(const AttnParams p) {
     const dim3 bid = ddpm::xcd_block();   // the block to work on: neighbours in launch order share an XCD's L2
-    if (F16 && bid.x == 0) attention_fwd_x3p_body<DQ, NCT, NW, F16, true>(p, bid);
+    if constexpr (PRE) attention_fwd_x3p_body<DQ, NCT, NW, F16, false, true>(p, bid);
+    else if (F16 && bid.x == 0) attention_fwd_x3p_body<DQ, NCT, NW, F16, true>(p, bid);
     else attention_fwd_x3p_body<DQ, NCT, NW, F16, false>(p, bid);
 }
 
-template <int DQ, int NCT, int NW, bool F16>
+template <int DQ, int NCT, int NW, bool F16, bool PRE = false>
 int launch_x3p_math(const AttnParams& p, int batch, hipStream_t s) {
     constexpr int KD = DQ < 16 ? 16 : DQ, NPL = F16 ? 2 : 3;
-    constexpr int lds = 3 * KT * (NPL * KD * 2 + 16) + 2 * NPL * KT * (32 * NCT * 2 + 64);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_x3p_kernel<DQ, NCT, NW, F16>),
+    constexpr int lds = 3 * KT * (NPL * KD * 2 + 16) + 2 * (PRE ? 16 * KT * 32 * NCT / 4 : NPL * KT * (32 * NCT * 2 + 64));
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_x3p_kernel<DQ, NCT, NW, F16, PRE>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return ddpm::fail_invalid("LDS size for the attention forward");
     const dim3 g((p.n + 32 * NW - 1) / (32 * NW), (p.c + 32 * NCT - 1) / (32 * NCT), batch);
-    attention_fwd_x3p_kernel<DQ, NCT, NW, F16><<<g, 64 * NW, lds, s>>>(p);
+    attention_fwd_x3p_kernel<DQ, NCT, NW, F16, PRE><<<g, 64 * NW, lds, s>>>(p);
     return ddpm::check_launch("attention_fwd_x3p_kernel");
 }
 
@@ -1118,6 +1165,44 @@ int launch_dq(const AttnParams& p, int batch, hipStream_t s) {
 
 }  // namespace
 
+namespace ddpm {
+
+// The two shapes with pair kernels behind them: 64 channels (two query blocks per wave) and 128 (software-pipelined),
+// when those are the kernels ddpm_attention_fwd itself would run.
+bool attention_fwd_pairs_fits(int batch, int n, int c, int dq) {
+    if (!f16_math() || batch > 65535 || (n & 31) != 0 || n < x3_min_n()) return false;
+    if (small_attention() && attention_small_fwd_fits(n, c, dq)) return false;
+    return (c == 64 && dq == 8) || (c == 128 && dq == 16 && pipelined_attention());
+}
+
+int attention_fwd_pairs(const float* qk, const unsigned char* vpl, const float* x, int ldx, const float* gamma, const float* temb,
+                        float* out, int ldo, int batch, int n, int c, int dq, hipStream_t s) {
+    if (!attention_fwd_pairs_fits(batch, n, c, dq)) return fail_invalid("attention_fwd_pairs: not a shape of the pair kernels");
+    AttnParams p;
+    p.qkv = qk;
+    p.vpl = vpl;
+    p.x = x;
+    p.gamma = gamma;
+    p.temb = temb;
+    p.out = out;
+    p.attn_raw = nullptr;
+    p.lse = nullptr;
+    p.n = n;
+    p.c = c;
+    p.dqp = dq;
+    p.lq = 2 * dq;
+    p.ldx = ldx;
+    p.ldo = ldo;
+    p.range_flag = range_flag();
+    if (!p.range_flag) return DDPM_E_LAUNCH;
+    if (c == 128) return launch_x3p_math<16, 4, 4, true, true>(p, batch, s);
+    const dim3 g((n + 255) / 256, 1, batch);
+    attention_fwd_x3_kernel<8, 2, 2, true, true><<<g, 256, 0, s>>>(p);
+    return check_launch("attention_fwd_x3_kernel (pairs)");
+}
+
+}  // namespace ddpm
+
 extern "C" int ddpm_attention_fwd(const float* qkv, const float* x, int ldx, const float* gamma, float* out, int ldo,
                                   float* attn_raw, float* lse, const float* temb, int batch, int n, int c, int dq,
                                   void* stream) {
@@ -1140,6 +1225,7 @@ extern "C" int ddpm_attention_fwd(const float* qkv, const float* x, int ldx, con
     p.lq = 2 * dq + c;
     p.ldx = ldx;
     p.ldo = ldo;
+    p.vpl = nullptr;
     p.range_flag = ddpm::f16_math() ? ddpm::range_flag() : nullptr;
     if (ddpm::f16_math() && !p.range_flag) return DDPM_E_LAUNCH;
     hipStream_t s = ddpm::as_stream(stream);

@@ -15,4 +15,11 @@ int attention_small_fwd(const float* qkv, const float* x, int ldx, const float* 
 int attention_small_bwd(const float* qkv, const float* dy, int ldd, const float* lse, const float* e, const float* gamma, float* dqkv,
                         int batch, int n, int c, int dq, hipStream_t s);
 
+// Attention forward of an inference call whose k and v the projection has already split into fp16 pairs (attention.hip;
+// layouts at AttnParams::vpl): qk = [rows][2 dq] (q as fp32, k as (hi | lo << 16) words), vpl = the v planes. The same
+// kernels, products and order of operations as ddpm_attention_fwd runs for these shapes: the same bits.
+bool attention_fwd_pairs_fits(int batch, int n, int c, int dq);
+int attention_fwd_pairs(const float* qk, const unsigned char* vpl, const float* x, int ldx, const float* gamma, const float* temb,
+                        float* out, int ldo, int batch, int n, int c, int dq, hipStream_t s);
+
 }  // namespace ddpm

@@ -56,12 +56,14 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, u32x4& hi
 // One wave's share: row groups g_begin + wr, + 4, ... of the workgroup's run, column blocks nb0 .. nb0 + NBW - 1.
 // WATCH: this wave watches the range of the activations it loads (F16); the two column halves load the same rows, so
 // the first half does the checking for both.
-template <int NBW, bool F16, bool WATCH>
+// PAIRS (F16 only): the epilogue writes k as (hi | lo << 16) words and v as pair planes (GemmParams::pair_v) and
+// watches the range of what it splits; every wave then has something to check.
+template <int NBW, bool F16, bool WATCH, bool PAIRS>
 __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned char* wsm, int wr, int nb0, int lane);
 
 // With F16 the operands are fp16 pairs (conv_common.h): planes 0 and 1 of the packed weights, three MFMAs per step and
 // block, the hi*hi products in `acc` and the cross products in `master`, scaled by 2^-11 and added in the epilogue.
-template <int NB0, int NB1, bool F16>   // column blocks of the waves of the first / second column half
+template <int NB0, int NB1, bool F16, bool PAIRS = false>   // column blocks of the waves of the first / second column half
 __global__ __launch_bounds__(kThreads, 1) void conv1x1_resident_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];   // [chunk][column block][plane][lane][16 B]
     if constexpr (F16) fp16_saturate();
@@ -84,17 +86,18 @@ __global__ __launch_bounds__(kThreads, 1) void conv1x1_resident_kernel(const Gem
     }
     __syncthreads();
     // the two column halves hold different numbers of blocks: each gets its own straight-line code
-    if (wn == 0) wave_body<NB0, F16, true>(p, wsm, wr, 0, lane);
-    else if (NB1 > 0) wave_body<(NB1 > 0 ? NB1 : 1), F16, false>(p, wsm, wr, NB0, lane);
+    if (wn == 0) wave_body<NB0, F16, true, PAIRS>(p, wsm, wr, 0, lane);
+    else if (NB1 > 0) wave_body<(NB1 > 0 ? NB1 : 1), F16, false, PAIRS>(p, wsm, wr, NB0, lane);
 }
 
-template <int NBW, bool F16, bool WATCH>
+template <int NBW, bool F16, bool WATCH, bool PAIRS>
 __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned char* wsm, int wr, int nb0, int lane) {
     const int r = lane & 31, h = lane >> 5;
     const int g_begin = __builtin_amdgcn_readfirstlane(blockIdx.x * p.gpb);
     const int g_end = __builtin_amdgcn_readfirstlane(min(p.groups_total, g_begin + p.gpb));
     if (g_begin + wr >= g_end) return;
-    std::conditional_t<WATCH, RangeWatch, NoWatch> amax;   // F16: largest magnitude this thread has turned into an fp16 pair
+    std::conditional_t<WATCH || PAIRS, RangeWatch, NoWatch> amax;   // F16: largest magnitude this thread has turned into an fp16 pair
+    static_assert(F16 || !PAIRS, "the pair epilogue belongs to the fp16-pair arithmetic");
 
     const int kc16 = p.kc16;
     const int ntile = (g_end - g_begin - wr + 3) >> 2;        // row groups g_begin + wr, + 4, ...
@@ -155,8 +158,11 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
 
     auto step = [&](f32x4 (&raw)[2], u32x4 (&b0cur)[NBW], u32x4 (&b0next)[NBW]) {
         u32x4 a0, a1, a2;
-        if constexpr (F16) split8_f16(raw[0], raw[1], a0, a1, amax);
-        else split8(raw[0], raw[1], a0, a1, a2);
+        if constexpr (F16 && WATCH) split8_f16(raw[0], raw[1], a0, a1, amax);
+        else if constexpr (F16) {
+            NoWatch none;
+            split8_f16(raw[0], raw[1], a0, a1, none);
+        } else split8(raw[0], raw[1], a0, a1, a2);
         kc = __builtin_amdgcn_readfirstlane(kc);
         t = __builtin_amdgcn_readfirstlane(t);
         if (!(DDPM_C1R_ABLATE & 2)) load_a(raw);              // this register set now carries step s + 4
@@ -226,6 +232,45 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
                     float v[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] = master[j][e] * sc + sh;
+                    if constexpr (PAIRS) {
+                        // (no residual, no activation in this mode: the launcher checks)
+                        if (n >= p.pair_from) {
+                            // v: registers 8ck .. 8ck + 7 are rows 16ck + 4h + i and 16ck + 8 + 4h + i (i < 4) of the
+                            // group, the eight keys that half h of a matrix operand takes from 16-key chunk ck: one
+                            // 16-byte store per chunk and plane at [chunk][h][plane][channel]
+                            const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
+                                p.pair_v + m0 * p.pair_c * 4ll, 0, static_cast<unsigned>(32 * p.pair_c * 4), 0x00020000);
+                            const unsigned ch16 = static_cast<unsigned>(n - p.pair_from) * 16u;
+                            const unsigned pc16 = static_cast<unsigned>(p.pair_c) * 16u;
+#pragma unroll
+                            for (int ck = 0; ck < 2; ++ck) {
+                                u32x4 ph, pl;
+                                split8_f16(f32x4{v[8 * ck], v[8 * ck + 1], v[8 * ck + 2], v[8 * ck + 3]},
+                                           f32x4{v[8 * ck + 4], v[8 * ck + 5], v[8 * ck + 6], v[8 * ck + 7]}, ph, pl, amax);
+                                const unsigned o = static_cast<unsigned>((ck * 2 + (hq >> 2)) * 2) * pc16 + ch16;
+                                __builtin_amdgcn_raw_buffer_store_b128(ph, rs_v, o, 0, DDPM_STORE_AUX);
+                                __builtin_amdgcn_raw_buffer_store_b128(pl, rs_v, o + pc16, 0, DDPM_STORE_AUX);
+                            }
+                        } else {
+                            if (2 * n >= p.pair_from) {   // k: each element as (hi | lo << 16)
+#pragma unroll
+                                for (int e = 0; e < 16; e += 2) {
+                                    unsigned hh, ll;
+                                    watch2(amax, f32x2{v[e], v[e + 1]});
+                                    split2_pair(f32x2{v[e], v[e + 1]}, hh, ll);
+                                    v[e] = __builtin_bit_cast(float, __builtin_amdgcn_perm(ll, hh, 0x05040100u));
+                                    v[e + 1] = __builtin_bit_cast(float, __builtin_amdgcn_perm(ll, hh, 0x07060302u));
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const unsigned row = static_cast<unsigned>((e & 3) + 8 * (e >> 2) + hq);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_o, row * ldo4 + n4, 0, DDPM_STORE_AUX);
+                            }
+                        }
+                        zero(master[j]);
+                        continue;
+                    }
                     if (p.residual) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
@@ -267,7 +312,7 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
     if (s < nsteps) step(ra[0], bw0[0], bw0[1]);
     if (s + 1 < nsteps) step(ra[1], bw0[1], bw0[0]);
     if (s + 2 < nsteps) step(ra[2], bw0[0], bw0[1]);
-    if constexpr (F16 && WATCH) raise_range_flag(p.range_flag, amax);
+    if constexpr (F16 && (WATCH || PAIRS)) raise_range_flag(p.range_flag, amax);
 }
 
 template <int NB0, int NB1, bool F16>
@@ -612,6 +657,36 @@ int launch_conv1x1_resident(GemmParams& p, hipStream_t s) {
         case 5: return launch_one<3, 2>(p, grid, lds, s);
         default: return launch_one<3, 3>(p, grid, lds, s);
     }
+}
+
+// The q|k|v projection of an inference-time attention block with its k and v columns written as fp16 pairs. Takes what
+// the resident kernel takes in the fp16-pair arithmetic, for the two shapes that have pair-consuming attention kernels
+// behind them (q|k of 8 + 8 or 16 + 16 columns, v of 64 or 128): 3 or 5 column blocks. Whole row groups only.
+int launch_conv1x1_pairs(GemmParams& p, hipStream_t s) {
+    if (!f16_math() || p.c2 > 0 || p.temb || p.residual || p.scale || p.act != DDPM_ACT_NONE || p.m_total < 16384 || (p.ctot & 3) != 0) return 1;
+    if ((p.m_total & 31) != 0 || !p.pair_v || p.n_total != p.pair_from + p.pair_c || p.ldo != p.pair_from) return 1;
+    if (!p.range_flag) return DDPM_E_LAUNCH;
+    p.kc16 = (p.ctot + XK - 1) / XK;
+    p.nbp = (p.n_total + 31) / 32;
+    const long long wb = 3072ll * p.nbp * p.kc16;
+    if ((p.nbp != 3 && p.nbp != 5) || wb > kMaxWeightLds) return 1;
+    p.w_bytes = static_cast<unsigned>(wb);
+    p.groups_total = p.m_total / 32;
+    const int gpb = (p.groups_total + 255) / 256;
+    p.gpb = gpb;
+    if (static_cast<long long>(gpb) * 32 * (p.ld1 > p.n_total ? p.ld1 : p.n_total) * 4ll >= 0x7fffffffll) return 1;
+    const int grid = (p.groups_total + gpb - 1) / gpb;
+    const int lds = static_cast<int>(wb);
+    auto go = [&](auto kernel, const char* what) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxWeightLds) != hipSuccess) {
+            set_error("%s: cannot reserve %d bytes of LDS", what, kMaxWeightLds);
+            return static_cast<int>(DDPM_E_LAUNCH);
+        }
+        kernel<<<dim3(grid), dim3(kThreads), lds, s>>>(p);
+        return check_launch(what);
+    };
+    if (p.nbp == 3) return go(&conv1x1_resident_kernel<2, 1, true, true>, "conv1x1_resident_kernel (pairs, 3 blocks)");
+    return go(&conv1x1_resident_kernel<3, 2, true, true>, "conv1x1_resident_kernel (pairs, 5 blocks)");
 }
 
 }  // namespace conv

@@ -51,6 +51,11 @@ struct GemmParams {
     unsigned* range_flag;                // fp16-pair kernels: raised when an operand lies beyond fp16's range
     double* stat_partial;                // halo kernel, optional: per-channel partial sums of the values written, [block][sum | sum of squares][cout]
     int stat_blocks;                     // set by the launcher: number of blocks in stat_partial
+    // launch_conv1x1_pairs only (the q|k|v projection of an inference-time attention block): columns from pair_from on
+    // (v) go to pair_v as fp16-pair planes in the order the attention kernels' matrix operands take them, columns
+    // pair_from / 2 .. pair_from - 1 (k) stay in `out` as one (hi | lo << 16) word per element
+    unsigned char* pair_v;
+    int pair_from, pair_c;
 };
 
 static __device__ __forceinline__ float apply_act(float v, int act) {
@@ -232,6 +237,8 @@ int launch_conv3x3_halo(GemmParams& p, hipStream_t s);
 // 1x1 convolution with the whole packed weight matrix resident in LDS and the activations loaded straight
 // into MFMA operand registers (conv1x1_resident.hip). Same return convention as launch_conv3x3_halo.
 int launch_conv1x1_resident(GemmParams& p, hipStream_t s);
+// The same kernel with the pair epilogue (GemmParams::pair_v); 1 = not a shape it takes, nothing launched.
+int launch_conv1x1_pairs(GemmParams& p, hipStream_t s);
 
 // DDPM_CONV1X1_RESIDENT=0 (read once) keeps every 1x1 convolution on the generic GEMM kernel: a diagnostic
 // switch for A/B measurements.

@@ -28,6 +28,7 @@
 #include <cstring>
 #include <type_traits>
 
+#include "attention_small.h"
 #include "conv_common.h"
 
 using ddpm::as_stream;
@@ -1173,6 +1174,42 @@ extern "C" int ddpm_conv1x1_fwd(const ddpm_conv_desc* d, const float* src1, cons
         if (rc <= 0) return rc;   // launched, or failed; positive = shape for the generic kernel
     }
     return launch_gemm<MODE_CONV1>(p, as_stream(stream));
+}
+
+extern "C" int ddpm_self_attention_infer(const float* x, int ldx, const float* wqkv_packed, const float* bias_qkv, const float* gamma,
+                                         const float* temb, float* out, int ldo, float* workspace, int batch, int n, int c, int dq,
+                                         void* stream) {
+    DDPM_REQUIRE(x && wqkv_packed && bias_qkv && gamma && out && workspace && batch > 0 && n > 0 && c > 0 && dq > 0);
+    DDPM_REQUIRE(static_cast<int64_t>(batch) * n < (1ll << 31) && ddpm::aligned16(workspace));
+    ddpm_conv_desc d = {};
+    d.batch = batch;
+    d.in_h = n;
+    d.in_w = 1;
+    d.c1 = c;
+    d.ld1 = ldx;
+    d.cout = 2 * dq + c;
+    d.ldo = d.cout;
+    d.act = DDPM_ACT_NONE;
+    d.out_h = n;
+    d.out_w = 1;
+    ddpm_epilogue ep = {};
+    ep.shift = bias_qkv;
+    if (split_math() && resident_1x1() && ddpm::attention_fwd_pairs_fits(batch, n, c, dq)) {
+        if (int rc = validate_common(&d, x, nullptr, wqkv_packed, &ep, workspace)) return rc;
+        GemmParams p;
+        fill_common(p, &d, x, nullptr, wqkv_packed, &ep, workspace);
+        p.taps = 1;
+        p.ldo = 2 * dq;
+        p.pair_from = 2 * dq;
+        p.pair_c = c;
+        p.pair_v = reinterpret_cast<unsigned char*>(workspace + static_cast<int64_t>(batch) * n * 2 * dq);
+        const int rc = launch_conv1x1_pairs(p, as_stream(stream));
+        if (rc < 0) return rc;
+        if (rc == 0)
+            return ddpm::attention_fwd_pairs(workspace, p.pair_v, x, ldx, gamma, temb, out, ldo, batch, n, c, dq, as_stream(stream));
+    }
+    if (int rc = ddpm_conv1x1_fwd(&d, x, nullptr, wqkv_packed, &ep, workspace, stream)) return rc;
+    return ddpm_attention_fwd(workspace, x, ldx, gamma, out, ldo, nullptr, nullptr, temb, batch, n, c, dq, stream);
 }
 
 extern "C" int ddpm_convT2x2_fwd(const ddpm_conv_desc* d, const float* src, const float* w_packed, const ddpm_epilogue* ep,

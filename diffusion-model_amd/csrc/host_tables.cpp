@@ -17,7 +17,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace ddpm
 
 extern "C" const char* ddpm_last_error(void) { return ddpm::g_err; }
-extern "C" int ddpm_abi_version(void) { return 4; }
+extern "C" int ddpm_abi_version(void) { return 5; }
 
 // numpy.linspace(start, stop, n) in float64: step = (stop-start)/(n-1), y[i] = i*step + start,
 // last element forced to stop.

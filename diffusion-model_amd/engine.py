@@ -21,6 +21,9 @@ from .engine_train import TrainMixin, UNetFunction
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 BN_EPS = 1e-5
+# DDPM_ATTN_FUSED=0 (read once): inference-time attention blocks run as ddpm_conv1x1_fwd + ddpm_attention_fwd, as training
+# calls do, instead of ddpm_self_attention_infer: a diagnostic switch for A/B measurements (the results are the same bits).
+_FUSED_ATTENTION = os.environ.get("DDPM_ATTN_FUSED", "1") != "0"
 
 
 def _ptr(t):
@@ -516,13 +519,19 @@ class UNetEngine(TrainMixin):
         if dqp not in (8, 16, 32, 64, 128):
             raise NotImplementedError(f"attention with C/8 = {c // 8} query channels is not supported (at most 128: base_channels 128)")
         qkv = View(self._new(b, h, w, 2 * dqp + c, x.buf))
+        n = h * w
+        if save is None and _FUSED_ATTENTION:
+            # inference: projection and attention behind one entry point, which may hand k and v over as fp16 pairs
+            self._launch("self_attention<inference>", 2.0 * b * n * (2 * dqp + c) * c + 2.0 * b * n * n * (dqp + c),
+                         "ddpm_self_attention_infer", x.ptr, x.ld, _ptr(wq), _ptr(bq), _ptr(self.T(key + ".gamma")), _ptr(temb),
+                         out.ptr, out.ld, qkv.ptr, b, n, c, dqp, _stream())
+            return
         self.conv1x1(x, wq, bq, 2 * dqp + c, qkv)
         raw = lse = None
         if save is not None:
             raw = torch.empty((b, h, w, c), device=x.buf.device, dtype=torch.float32)
             lse = torch.empty((b, h * w), device=x.buf.device, dtype=torch.float32)
             save.update(qkv=qkv, raw=raw, lse=lse)
-        n = h * w
         # mirrors the library's choice of kernel family (profiling label only)
         math = conv_math()
         label = "attention_fwd<fp32>"

@@ -338,6 +338,19 @@ int ddpm_attention_fwd(const float* qkv, const float* x, int ldx, const float* g
                        int ldo, float* attn_raw, float* lse, const float* temb, int batch, int n, int c,
                        int dq, void* stream);
 
+/* The whole attention block of an INFERENCE call in one entry: the fused q|k|v projection (weights and bias from
+ * ddpm_pack_qkv) followed by the attention above, out = gamma * softmax(Q K^T) V + x (+ temb). Nothing is kept for a
+ * backward pass, so the layout of the projection's output is the library's own affair: for the shapes whose attention
+ * kernels take fp16 pairs (C = 64 or 128, N a multiple of 32, at least 16384 rows, default arithmetic) the projection's
+ * epilogue writes k and v already split, in the order the attention kernels' matrix operands take them, instead of
+ * every query block of every sample splitting them again on its way to LDS; the same pairs, products and order of
+ * operations, so the same bits as ddpm_conv1x1_fwd + ddpm_attention_fwd, which it runs for every other shape.
+ * x/out: [B][N][.] with strides ldx/ldo; workspace: B*N*(2*dq + C) floats, 16-byte aligned, contents unspecified
+ * afterwards. Replaces SelfAttention.forward under torch.no_grad(), second-iteration/unet.py:45-61. */
+int ddpm_self_attention_infer(const float* x, int ldx, const float* wqkv_packed, const float* bias_qkv,
+                              const float* gamma, const float* temb, float* out, int ldo, float* workspace,
+                              int batch, int n, int c, int dq, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Train-mode BatchNorm2d (+ activation / residual / time-embedding add), forward and backward.
  * Replaces nn.BatchNorm2d in training mode together with the ReLU/GELU, the residual add of

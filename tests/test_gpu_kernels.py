@@ -419,6 +419,48 @@ def test_attention_fwd_inference_call(case):
     assert_close(out.cpu(), out2.cpu().double(), TOL, f"attention, inference against training call {case}")
 
 
+@pytest.mark.parametrize("case", [(16, 1024, 128, True), (64, 256, 128, False), (16, 1024, 64, True), (66, 256, 64, False),
+                                  # shapes that the entry hands to the two plain calls: few rows, N not a multiple of 32, 256 channels
+                                  (2, 256, 128, True), (24, 784, 128, True), (64, 256, 256, False)])
+def test_self_attention_infer_is_projection_plus_attention(case):
+    """ddpm_self_attention_infer against ddpm_conv1x1_fwd + ddpm_attention_fwd on the same packed weights: the same BITS,
+    whether it hands k and v over as fp16 pairs (the first four shapes in the default arithmetic) or runs the two calls
+    itself; and against the float64 attention of the float64 projection to the usual tolerance."""
+    B, N, c, with_temb = case
+    dq = c // 8
+    dqp = (dq + 7) // 8 * 8
+    lq = 2 * dqp + c
+    x = rnd((B, N, c), 31)
+    qw, kw, vw = rnd((dq, c), 32, c ** -0.5), rnd((dq, c), 33, 2.0 * c ** -0.5), rnd((c, c), 34, c ** -0.5)
+    qb, kb, vb = rnd((dq,), 35, 0.1), rnd((dq,), 36, 0.1), rnd((c,), 37, 0.1)
+    gamma, temb = torch.tensor([0.43]), rnd((B, c), 38)
+    keep = [t.cuda() for t in (qw, kw, vw, qb, kb, vb, x, gamma, temb)]
+    wf = torch.empty(packed_floats(1, lq, c), device="cuda")
+    wt = torch.empty(packed_floats(1, c, lq), device="cuda")
+    bias = torch.empty(lq, device="cuda")
+    call("ddpm_pack_qkv", *(P(t) for t in keep[:6]), c, dq, dqp, P(wf), P(wt), P(bias), stream())
+    tp = P(keep[8]) if with_temb else None
+    # the two calls
+    qkv = torch.empty((B, N, lq), device="cuda")
+    d = ConvDesc(batch=B, in_h=N, in_w=1, c1=c, ld1=c, c2=0, ld2=0, cout=lq, ldo=lq, act=0, ldr=0, out_h=N, out_w=1, off_y=0, off_x=0)
+    ep = Epilogue(None, P(bias), None, None)
+    call("ddpm_conv1x1_fwd", C.byref(d), P(keep[6]), None, P(wf), C.byref(ep), P(qkv), stream())
+    two = torch.full((B, N, c), float("nan"), device="cuda")
+    call("ddpm_attention_fwd", P(qkv), P(keep[6]), c, P(keep[7]), P(two), c, None, None, tp, B, N, c, dqp, stream())
+    # the one entry
+    ws = torch.full((B, N, lq), float("nan"), device="cuda")
+    one = torch.full((B, N, c), float("nan"), device="cuda")
+    call("ddpm_self_attention_infer", P(keep[6]), c, P(wf), P(bias), P(keep[7]), tp, P(one), c, P(ws), B, N, c, dqp, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), f"{case}: {(one - two).abs().max().item():.3e} apart"
+    xd = x.double()
+    q, k, v = xd @ qw.double().T + qb.double(), xd @ kw.double().T + kb.double(), xd @ vw.double().T + vb.double()
+    want = gamma.double() * torch.bmm(torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1), v) + xd
+    if with_temb:
+        want = want + temb.double()[:, None, :]
+    assert_close(one.cpu(), want, TOL, f"self-attention block {case}")
+
+
 def test_attention_large_logits_rescale():
     """One key dominates from a late tile on: forces the online-softmax rescale branch."""
     B, N, c, dq = 1, 160, 32, 8

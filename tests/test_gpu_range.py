@@ -417,6 +417,44 @@ def test_attention_forward_and_backward_flag_a_bad_element_anywhere(b, n, c, dq)
 
 
 @pair_default
+@pytest.mark.parametrize("b,n,c", [(16, 1024, 128), (64, 256, 64), (3, 256, 128)])
+def test_self_attention_infer_flags_what_its_projection_splits(b, n, c):
+    """The fused inference entry splits k and v in the projection's epilogue (first two shapes; the third runs the two plain
+    calls): a q, k or v column pushed beyond fp16's range through its bias, or one input element, must raise the flag."""
+    dq = c // 8
+    dqp = (dq + 7) // 8 * 8
+    lq = 2 * dqp + c
+    x = torch.randn((b, n, c), device="cuda")
+    ws_ = [torch.randn((r, c), device="cuda") * c ** -0.5 for r in (dq, dq, c)]
+    bs_ = [torch.zeros(r, device="cuda") for r in (dq, dq, c)]
+    wf, wt = torch.empty(packed_floats(1, lq, c), device="cuda"), torch.empty(packed_floats(1, c, lq), device="cuda")
+    bias, gamma = torch.empty(lq, device="cuda"), torch.tensor([0.5], device="cuda")
+    call("ddpm_pack_qkv", *(P(t) for t in ws_), *(P(t) for t in bs_), c, dq, dqp, P(wf), P(wt), P(bias), stream())
+    out, ws = torch.empty((b, n, c), device="cuda"), torch.empty((b, n, lq), device="cuda")
+
+    def run():
+        call("ddpm_self_attention_infer", P(x), c, P(wf), P(bias), P(gamma), None, P(out), c, P(ws), b, n, c, dqp, stream())
+
+    read_flag()
+    run()
+    assert read_flag() == 0
+    for col in (0, dq - 1, dqp, dqp + dq - 1, 2 * dqp, 2 * dqp + 17, lq - 1):
+        keep = bias[col].item()
+        bias[col] = 1.0e5
+        run()
+        assert read_flag() == 1, ("bias of column", col)
+        bias[col] = keep
+    for pos in _positions(x.shape, 4, 6):
+        keep = x[pos].item()
+        x[pos] = -8.0e4
+        run()
+        assert read_flag() == 1, ("input", pos)
+        x[pos] = keep
+    run()
+    assert read_flag() == 0
+
+
+@pair_default
 @pytest.mark.parametrize("fuse", [True, False])
 def test_guided_sampling_falls_back_as_a_whole_segment(fuse):
     """Classifier-free guidance calls the network twice per step (third-iteration/diffusion.py:34-41), once through the
