@@ -6,6 +6,7 @@
     python tools/microbench.py conv1x1 B H W Cin Cout [iters]
     python tools/microbench.py convT   B H W Cin Cout [iters]  (2x2 stride-2 transposed conv into the right half of a [B,2H,2W,2*Cout] buffer)
     python tools/microbench.py attn    B N C [iters]         (forward + backward)
+    python tools/microbench.py attnblock B N C [iters]       (inference attention block: q|k|v projection + attention, one entry)
     python tools/microbench.py step    NELEMS [iters]        (reverse-step kernel, HBM-bound)
 Prints the average launch time from HIP events and the achieved TFLOP/s or GB/s.
 """
@@ -117,6 +118,24 @@ def main():
         import hashlib
         digest = hashlib.sha1(dqkv.cpu().numpy().tobytes() + out.cpu().numpy().tobytes()).hexdigest()[:12]
         print(f"attn bwd B={B} N={N} C={c}: {t*1e6:.1f} us  {2.0*B*N*N*(3*dq+3*c)/t/1e12:.1f} TFLOP/s (algorithmic, no recompute)  outputs {digest}")
+    elif kind == "attnblock":
+        import hashlib
+        B, N, c = a[:3]
+        iters = a[3] if len(a) > 3 else 10
+        dq = c // 8
+        dqp = (dq + 7) // 8 * 8
+        lq = 2 * dqp + c
+        torch.manual_seed(2)
+        x = torch.randn(B, N, c, device=dev)
+        ws_ = [torch.randn(r, c, device=dev) * c ** -0.5 for r in (dq, dq, c)]
+        bs_ = [torch.randn(r, device=dev) * 0.1 for r in (dq, dq, c)]
+        wf, wt = torch.empty(packed_floats(1, lq, c), device=dev), torch.empty(packed_floats(1, c, lq), device=dev)
+        bias, g = torch.empty(lq, device=dev), torch.full((1,), 0.5, device=dev)
+        call("ddpm_pack_qkv", *(P(t) for t in ws_), *(P(t) for t in bs_), c, dq, dqp, P(wf), P(wt), P(bias), S())
+        out, ws = torch.empty(B, N, c, device=dev), torch.empty(B, N, lq, device=dev)
+        t = timeit(lambda: call("ddpm_self_attention_infer", P(x), c, P(wf), P(bias), P(g), None, P(out), c, P(ws), B, N, c, dqp, S()), iters)
+        digest = hashlib.sha1(out[:8].cpu().numpy().tobytes()).hexdigest()[:12]
+        print(f"attention block B={B} N={N} C={c}: {t*1e6:.1f} us  {(2.0*B*N*lq*c + 2.0*B*N*N*(dqp+c))/t/1e12:.1f} TFLOP/s  {digest}")
     elif kind == "step":
         n = a[0]
         iters = a[1] if len(a) > 1 else 50
