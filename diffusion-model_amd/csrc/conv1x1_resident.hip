@@ -659,6 +659,20 @@ int launch_conv1x1_resident(GemmParams& p, hipStream_t s) {
     }
 }
 
+namespace {
+template <int NB0, int NB1>
+int launch_pairs(const GemmParams& p, int grid, int lds, hipStream_t s) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_resident_kernel<NB0, NB1, true, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxWeightLds);
+    if (attr != hipSuccess) {
+        set_error("conv1x1_resident_kernel (pairs): cannot reserve %d bytes of LDS: %s", kMaxWeightLds, hipGetErrorString(attr));
+        return DDPM_E_LAUNCH;
+    }
+    conv1x1_resident_kernel<NB0, NB1, true, true><<<dim3(grid), dim3(kThreads), lds, s>>>(p);
+    return check_launch("conv1x1_resident_kernel (pairs)");
+}
+}  // namespace
+
 // The q|k|v projection of an inference-time attention block with its k and v columns written as fp16 pairs. Takes what
 // the resident kernel takes in the fp16-pair arithmetic, for the two shapes that have pair-consuming attention kernels
 // behind them (q|k of 8 + 8 or 16 + 16 columns, v of 64 or 128): 3 or 5 column blocks. Whole row groups only.
@@ -677,16 +691,7 @@ int launch_conv1x1_pairs(GemmParams& p, hipStream_t s) {
     if (static_cast<long long>(gpb) * 32 * (p.ld1 > p.n_total ? p.ld1 : p.n_total) * 4ll >= 0x7fffffffll) return 1;
     const int grid = (p.groups_total + gpb - 1) / gpb;
     const int lds = static_cast<int>(wb);
-    auto go = [&](auto kernel, const char* what) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxWeightLds) != hipSuccess) {
-            set_error("%s: cannot reserve %d bytes of LDS", what, kMaxWeightLds);
-            return static_cast<int>(DDPM_E_LAUNCH);
-        }
-        kernel<<<dim3(grid), dim3(kThreads), lds, s>>>(p);
-        return check_launch(what);
-    };
-    if (p.nbp == 3) return go(&conv1x1_resident_kernel<2, 1, true, true>, "conv1x1_resident_kernel (pairs, 3 blocks)");
-    return go(&conv1x1_resident_kernel<3, 2, true, true>, "conv1x1_resident_kernel (pairs, 5 blocks)");
+    return p.nbp == 3 ? launch_pairs<2, 1>(p, grid, lds, s) : launch_pairs<3, 2>(p, grid, lds, s);
 }
 
 }  // namespace conv
