@@ -520,9 +520,15 @@ class UNetEngine(TrainMixin):
             raise NotImplementedError(f"attention with C/8 = {c // 8} query channels is not supported (at most 128: base_channels 128)")
         qkv = View(self._new(b, h, w, 2 * dqp + c, x.buf))
         n = h * w
+        # mirrors the library's choice of kernel family (profiling label only)
+        math = conv_math()
+        tag = "fp32"
+        if n >= 128 and c >= 64 and math != "fp32" and dqp <= 64:
+            pair = math == "f16x2" and dqp <= 16 and (save is None or os.environ.get("DDPM_ATTN_TRAIN_F16", "1") != "0")
+            tag = "fp16-pair" if pair else "split-bf16"
         if save is None and _FUSED_ATTENTION:
             # inference: projection and attention behind one entry point, which may hand k and v over as fp16 pairs
-            self._launch("self_attention<inference>", 2.0 * b * n * (2 * dqp + c) * c + 2.0 * b * n * n * (dqp + c),
+            self._launch(f"self_attention<inference,{tag}>", 2.0 * b * n * (2 * dqp + c) * c + 2.0 * b * n * n * (dqp + c),
                          "ddpm_self_attention_infer", x.ptr, x.ld, _ptr(wq), _ptr(bq), _ptr(self.T(key + ".gamma")), _ptr(temb),
                          out.ptr, out.ld, qkv.ptr, b, n, c, dqp, _stream())
             return
@@ -532,13 +538,7 @@ class UNetEngine(TrainMixin):
             raw = torch.empty((b, h, w, c), device=x.buf.device, dtype=torch.float32)
             lse = torch.empty((b, h * w), device=x.buf.device, dtype=torch.float32)
             save.update(qkv=qkv, raw=raw, lse=lse)
-        # mirrors the library's choice of kernel family (profiling label only)
-        math = conv_math()
-        label = "attention_fwd<fp32>"
-        if n >= 128 and c >= 64 and math != "fp32" and dqp <= 64:
-            pair = math == "f16x2" and dqp <= 16 and (lse is None or os.environ.get("DDPM_ATTN_TRAIN_F16", "1") != "0")
-            label = "attention_fwd<fp16-pair>" if pair else "attention_fwd<split-bf16>"
-        self._launch(label, 2.0 * b * n * n * (dqp + c), "ddpm_attention_fwd", qkv.ptr, x.ptr, x.ld,
+        self._launch(f"attention_fwd<{tag}>", 2.0 * b * n * n * (dqp + c), "ddpm_attention_fwd", qkv.ptr, x.ptr, x.ld,
                      _ptr(self.T(key + ".gamma")), out.ptr, out.ld, _ptr(raw), _ptr(lse), _ptr(temb), b, n, c, dqp, _stream())
 
     # ------------------------------------------------------------------ whole network, eval mode
