@@ -67,6 +67,31 @@ def test_full_width_unet_eval(variant, meta):
         assert_close(out.cpu(), torch.from_numpy(g[f"hw{hw}_out"]), TOL, f"v{variant} {hw} eps")
 
 
+@pytest.mark.parametrize("variant", [2, 3])
+def test_full_width_eval_with_pair_attention_blocks_is_the_two_call_forward(variant, monkeypatch):
+    """At 16 images of 32 x 32 the 64- and 128-channel attention blocks of an inference call (16384 rows each) hand k and v
+    over as fp16 pairs inside ddpm_self_attention_infer; the forward must give the bits of the forward that issues the
+    projection and the attention as two calls, outputs and all seven feature maps. (At 28 x 28 -- N = 784 is not a
+    multiple of 32 -- the entry runs the two calls itself; checked too.)"""
+    from diffusion_model_amd import engine
+    m = build(variant, 64, 128, 50 + variant)
+    for hw in (32, 28):
+        g = torch.Generator().manual_seed(hw)
+        c = 3 if variant == 3 else 1
+        x = torch.randn((16, c, hw, hw), generator=g).cuda()
+        t = torch.randint(0, 1000, (16,), generator=g).cuda()
+        args = [x, t] + ([torch.randint(0, 10, (16,), generator=g).cuda()] if variant == 3 else [])
+        got = {}
+        for fused in (True, False):
+            monkeypatch.setattr(engine, "_FUSED_ATTENTION", fused)
+            with torch.no_grad():
+                out = m(*args)
+            got[fused] = [out.clone()] + [f.clone() for f in m.feature_maps]
+        assert len(got[True]) == 8
+        for i, (a, b) in enumerate(zip(got[True], got[False])):
+            assert torch.equal(a, b), (variant, hw, i, (a - b).abs().max().item())
+
+
 class Recorder:
     def __init__(self, model):
         self.model, self.calls = model, []
