@@ -211,6 +211,7 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
         }
         if (last) {
             // ---- epilogue of row group g: bias / folded BatchNorm, residual, activation ----------------
+            if (PAIRS && p.nbp > 3) __builtin_amdgcn_s_setprio(0);
             // (wave-uniform by construction; said explicitly so that the descriptors below are built from scalars)
             const int g = __builtin_amdgcn_readfirstlane(g_begin + wr + 4 * t);
             const long long m0 = static_cast<long long>(g) * 32;
@@ -294,6 +295,7 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
                 }
                 zero(master[j]);
             }
+            if (PAIRS && p.nbp > 3) __builtin_amdgcn_s_setprio(2);
             kc = 0;
             ++t;
         } else {
@@ -302,6 +304,11 @@ __device__ __forceinline__ void wave_body(const GemmParams& p, const unsigned ch
     };
 
     // four steps per iteration: the four activation register sets are named, not indexed
+    // (The pair epilogue is long vector work -- splitting 16 values per block. Raised priority for the waves that are in
+    // their steps keeps their loads and matrix instructions from queueing behind it: 1-2 % of the 128-channel attention
+    // block. With the plain epilogue, and with the pair epilogue of the three-block shape (64 channels), the same setting
+    // measured 1 % slower, so only the five-block pair variant has it.)
+    if (PAIRS && p.nbp > 3) __builtin_amdgcn_s_setprio(2);
     int s = 0;
     for (; s + 3 < nsteps; s += 4) {
         step(ra[0], bw0[0], bw0[1]);
