@@ -151,21 +151,12 @@ constexpr int XROW_F16 = 80;   // LDS bytes per tile row: two planes of 16 fp16 
 // they do in fp32.
 static __device__ __forceinline__ void fp16_saturate() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
 
-// lo = RN_fp16((v - hi) * 2^11) as fma(hi, -2^11, v * 2^11) rounded to fp16 by the mixed-precision FMA, which takes hi
-// straight from its fp16 register half and writes an fp16 half: four vector instructions per two elements instead of
-// six (convert back, subtract, scale, convert). v * 2^11 and the fused sum are exact, so the bits are those of the plain
-// sequence for every input, range limits, subnormal remainders, infinities and NaN included (tools/probe/split_mix.hip).
-static __device__ __forceinline__ unsigned pair_remainder(const unsigned hi, const f32x2 scaled) {
-    unsigned lo;
-    const float c = -kLoScale;
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(c), "v"(scaled[0]));
-    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(c), "v"(scaled[1]));
-    return lo;
-}
-
 static __device__ __forceinline__ void split2_pair(const f32x2 v, unsigned& hi, unsigned& lo) {
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-    lo = pair_remainder(hi, v * kLoScale);
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 rem = (v - __builtin_convertvector(h, f32x2)) * kLoScale;
+    const f16x2 l = __builtin_convertvector(rem, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
 }
 
 // Range watch of the fp16-pair kernels: every thread keeps the largest magnitude it has turned into a pair (one
