@@ -116,6 +116,28 @@ def test_adam_host_side_contract():
         ours.step()
 
 
+def test_self_attention_infer_refuses_bad_arguments_before_touching_the_gpu():
+    """The argument checks of the fused inference entry run before any HIP call: null operands, a workspace that is not
+    16-byte aligned and sizes that are not positive come back as DDPM_E_INVALID (-1) with a message, on a box without a GPU."""
+    import ctypes as C
+    L = _lib.lib()
+    buf = (C.c_float * 64)()
+    base = C.addressof(buf)
+    base += (-base) % 16
+    ok = C.c_void_p(base)
+    args = dict(x=ok, ldx=8, w=ok, bias=ok, gamma=ok, temb=None, out=ok, ldo=8, ws=ok, b=1, n=4, c=8, dq=8, stream=None)
+
+    def run(**change):
+        a = {**args, **change}
+        return L.ddpm_self_attention_infer(a["x"], a["ldx"], a["w"], a["bias"], a["gamma"], a["temb"], a["out"], a["ldo"], a["ws"], a["b"],
+                                           a["n"], a["c"], a["dq"], a["stream"])
+
+    for change in (dict(x=None), dict(w=None), dict(bias=None), dict(gamma=None), dict(out=None), dict(ws=None),
+                   dict(ws=C.c_void_p(base + 4)), dict(b=0), dict(n=0), dict(c=0), dict(dq=0)):
+        assert run(**change) == -1, change
+        assert L.ddpm_last_error()
+
+
 @pytest.mark.parametrize("iteration", ["first-iteration", "second-iteration", "3"])
 def test_launcher_runs_an_unchanged_script_on_the_drop_ins(tmp_path, iteration):
     """A script that sits NEXT TO modules named unet / diffusion / beta_scheduler / embeddings (as the reference's
